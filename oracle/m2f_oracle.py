@@ -1,0 +1,457 @@
+"""CPU oracle for the Mask2Former hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A functional, pure-torch (CPU, fp32) restatement of the arithmetic that the reference
+repository reaches through `transformers.Mask2FormerForUniversalSegmentation`
+(reference call sites: models/mask2former/train.py:196, models/metrics.py:56,
+models/mask2former/inference.py:27).  The algorithm lives in the un-vendored, un-pinned
+dependency `transformers` (installed here: 5.15.0); citations `HF:n` are lines of
+transformers/models/mask2former/modeling_mask2former.py, `TORCHF:n` of torch/nn/functional.py.
+
+Pinning: the reference holds no tests or golden vectors for this path.  This oracle is
+pinned by `tests/test_oracle_golden.py` against fixtures that `tests/golden/make_golden.py`
+produced in the build container by importing that dependency and running it on CPU.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module.  Nothing under `weed_instance_segmentation_amd/` does.
+
+Everything works on a flat `state_dict` with the dependency's parameter names, so no
+nn.Module structure is shared with the product.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+
+# ----------------------------------------------------------------------------- K1
+def bilinear_sample_zeros(img: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Bilinear sample of img (N, C, H, W) at pixel coordinates x, y (N, P), zero padding.
+
+    Pixel coordinate convention of `grid_sample(align_corners=False)`: pixel i's centre is at
+    i, so a normalised location u in [0,1] maps to u*W - 0.5 (HF:807, HF:822-824).
+    Independent of `F.grid_sample`; used to cross-check it and as the K4 sampler.
+    """
+    N, C, H, W = img.shape
+    x0 = torch.floor(x)
+    y0 = torch.floor(y)
+    fx = x - x0
+    fy = y - y0
+    x0 = x0.long()
+    y0 = y0.long()
+    flat = img.reshape(N, C, H * W)
+    out = torch.zeros(N, C, x.shape[1], dtype=img.dtype)
+    for dy, dx, wgt in ((0, 0, (1 - fy) * (1 - fx)), (0, 1, (1 - fy) * fx), (1, 0, fy * (1 - fx)), (1, 1, fy * fx)):
+        xi = x0 + dx
+        yi = y0 + dy
+        ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+        idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1))[:, None, :].expand(N, C, -1)
+        out = out + torch.gather(flat, 2, idx) * (wgt * ok)[:, None, :]
+    return out
+
+
+def msdeform_attn_core(value: torch.Tensor, level_hw: Sequence[Sequence[int]], loc: torch.Tensor,
+                       w: torch.Tensor) -> torch.Tensor:
+    """K1.  HF:798-837.  value (B,S,H,D), loc (B,Q,H,L,P,2) in [0,1] (x,y), w (B,Q,H,L,P) -> (B,Q,H*D)."""
+    B, S, H, D = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    out = torch.zeros(B, H, D, Q, dtype=value.dtype)
+    start = 0
+    for l, (hh, ww) in enumerate(level_hw):
+        hh, ww = int(hh), int(ww)
+        v = value[:, start:start + hh * ww].permute(0, 2, 3, 1).reshape(B * H, D, hh, ww)
+        start += hh * ww
+        grid = (2 * loc[:, :, :, l] - 1).permute(0, 2, 1, 3, 4).reshape(B * H, Q, P, 2)
+        s = F.grid_sample(v, grid, mode="bilinear", padding_mode="zeros", align_corners=False)  # (BH,D,Q,P)
+        wl = w[:, :, :, l].permute(0, 2, 1, 3).reshape(B * H, 1, Q, P)
+        out = out + (s * wl).sum(-1).view(B, H, D, Q)
+    return out.permute(0, 3, 1, 2).reshape(B, Q, H * D).contiguous()
+
+
+def msdeform_attn_core_explicit(value, level_hw, loc, w):
+    """Same as `msdeform_attn_core` with the bilinear gather written out (no grid_sample)."""
+    B, S, H, D = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    out = torch.zeros(B * H, D, Q, dtype=value.dtype)
+    start = 0
+    for l, (hh, ww) in enumerate(level_hw):
+        hh, ww = int(hh), int(ww)
+        v = value[:, start:start + hh * ww].permute(0, 2, 3, 1).reshape(B * H, D, hh, ww)
+        start += hh * ww
+        ll = loc[:, :, :, l].permute(0, 2, 1, 3, 4).reshape(B * H, Q * P, 2)
+        s = bilinear_sample_zeros(v, ll[..., 0] * ww - 0.5, ll[..., 1] * hh - 0.5).view(B * H, D, Q, P)
+        wl = w[:, :, :, l].permute(0, 2, 1, 3).reshape(B * H, 1, Q, P)
+        out = out + (s * wl).sum(-1)
+    return out.view(B, H, D, Q).permute(0, 3, 1, 2).reshape(B, Q, H * D).contiguous()
+
+
+def reference_points(level_hw, B, dtype=torch.float32):
+    """HF:1127-1156 with valid_ratios == 1 (the pixel decoder builds all-False padding masks, HF:1343-1345)."""
+    pts = []
+    for hh, ww in level_hw:
+        hh, ww = int(hh), int(ww)
+        ry, rx = torch.meshgrid(torch.linspace(0.5, hh - 0.5, hh, dtype=dtype),
+                                torch.linspace(0.5, ww - 0.5, ww, dtype=dtype), indexing="ij")
+        pts.append(torch.stack((rx.reshape(-1) / ww, ry.reshape(-1) / hh), -1))
+    ref = torch.cat(pts, 0)  # (S, 2)
+    return ref[None, :, None, :].expand(B, -1, len(level_hw), -1)
+
+
+def msdeform_attn_module(sd, prefix, hidden, pos, ref, level_hw, n_heads, n_points=4):
+    """a2.  HF:954-1014 (attention_mask all False -> no masked_fill)."""
+    B, S, dm = hidden.shape
+    L = len(level_hw)
+    hp = hidden + pos
+    value = F.linear(hidden, sd[prefix + "value_proj.weight"], sd[prefix + "value_proj.bias"])
+    value = value.view(B, S, n_heads, dm // n_heads)
+    off = F.linear(hp, sd[prefix + "sampling_offsets.weight"], sd[prefix + "sampling_offsets.bias"])
+    off = off.view(B, S, n_heads, L, n_points, 2)
+    aw = F.linear(hp, sd[prefix + "attention_weights.weight"], sd[prefix + "attention_weights.bias"])
+    aw = torch.softmax(aw.view(B, S, n_heads, L * n_points), -1).view(B, S, n_heads, L, n_points)
+    norm = torch.tensor([[ww, hh] for hh, ww in level_hw], dtype=torch.long)  # HF:994-998 (int64, then promoted)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    out = msdeform_attn_core(value, level_hw, loc, aw)
+    return F.linear(out, sd[prefix + "output_proj.weight"], sd[prefix + "output_proj.bias"]), aw
+
+
+# ----------------------------------------------------------------------------- K2
+def masked_attention_core(q, k, v, mask):
+    """K2 bare kernel.  q (B,H,Q,D) already scaled by 1/sqrt(D); k, v (B,H,N,D);
+    mask (B,Q,N) bool, True = blocked, shared by all heads (HF:2052).  A fully blocked row
+    attends everywhere (HF:1912-1914).  softmax(bias + q k^T) v  (TORCHF:6578-6600)."""
+    open_row = ~mask.all(-1, keepdim=True)
+    m = mask & open_row
+    s = torch.matmul(q, k.transpose(-1, -2))
+    s = s.masked_fill(m[:, None], float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), v)
+
+
+def masked_cross_attention(sd, prefix, query, key, value, mask, n_heads):
+    """a4.  nn.MultiheadAttention as called at HF:1644-1650; sequence-first inputs.
+    query (Q,B,E) = hidden + query_pos, key (N,B,E) = feat + pos, value (N,B,E) = feat."""
+    Q, B, E = query.shape
+    N = key.shape[0]
+    D = E // n_heads
+    Wq, Wk, Wv = sd[prefix + "in_proj_weight"].chunk(3)
+    bq, bk, bv = sd[prefix + "in_proj_bias"].chunk(3)
+    q = F.linear(query, Wq, bq).view(Q, B, n_heads, D).permute(1, 2, 0, 3) * (1.0 / math.sqrt(D))
+    k = F.linear(key, Wk, bk).view(N, B, n_heads, D).permute(1, 2, 0, 3)
+    v = F.linear(value, Wv, bv).view(N, B, n_heads, D).permute(1, 2, 0, 3)
+    ctx = masked_attention_core(q, k, v, mask)  # (B,H,Q,D)
+    ctx = ctx.permute(2, 0, 1, 3).reshape(Q, B, E)
+    return F.linear(ctx, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+# ----------------------------------------------------------------------------- K3
+def mask_einsum(emb, pix):
+    """K3.  HF:2046.  emb (B,Q,C), pix (B,C,H,W) -> (B,Q,H,W)."""
+    return torch.einsum("bqc,bchw->bqhw", emb, pix)
+
+
+def attention_mask_from_logits(logits, size):
+    """HF:2048-2054 without the x num_heads replication: True = blocked."""
+    a = F.interpolate(logits, size=tuple(int(s) for s in size), mode="bilinear", align_corners=False)
+    return (a.sigmoid().flatten(2) < 0.5)
+
+
+def mlp3(sd, prefix, x):
+    """Mask2FormerMLPPredictionHead, HF:1979-2015."""
+    x = F.relu(F.linear(x, sd[prefix + "0.0.weight"], sd[prefix + "0.0.bias"]))
+    x = F.relu(F.linear(x, sd[prefix + "1.0.weight"], sd[prefix + "1.0.bias"]))
+    return F.linear(x, sd[prefix + "2.0.weight"], sd[prefix + "2.0.bias"])
+
+
+def mask_predictor(sd, prefix, outputs, pix, size):
+    """a5.  HF:2040-2056.  outputs (Q,B,C)."""
+    emb = mlp3(sd, prefix + "mask_embedder.", outputs.transpose(0, 1))
+    logits = mask_einsum(emb, pix)
+    return logits, attention_mask_from_logits(logits, size)
+
+
+# ----------------------------------------------------------------------------- K4
+def sample_point(feat, pts):
+    """HF:245-274.  feat (N,C,H,W); pts (N,P,2) in [0,1] as (x,y) -> (N,C,P)."""
+    H, W = feat.shape[-2:]
+    return bilinear_sample_zeros(feat, pts[..., 0] * W - 0.5, pts[..., 1] * H - 0.5)
+
+
+def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_classes, points, w_class=2.0, w_mask=5.0, w_dice=5.0):
+    """K4, one image.  HF:444-472.  mask_logits (Q,h,w); class_logits (Q,C+1); tgt_masks (T,H,W);
+    tgt_classes (T,) int64; points (1,P,2).  Returns the (Q,T) fp32 cost matrix."""
+    Q = mask_logits.shape[0]
+    T = tgt_masks.shape[0]
+    P = points.shape[1]
+    prob = class_logits.softmax(-1)
+    cost_class = -prob[:, tgt_classes]
+    tm = sample_point(tgt_masks[:, None].to(mask_logits.dtype), points.expand(T, -1, -1)).squeeze(1)  # (T,P)
+    pm = sample_point(mask_logits[:, None], points.expand(Q, -1, -1)).squeeze(1)  # (Q,P)
+    # pair-wise sigmoid CE, HF:350-374
+    pos = F.binary_cross_entropy_with_logits(pm, torch.ones_like(pm), reduction="none")
+    neg = F.binary_cross_entropy_with_logits(pm, torch.zeros_like(pm), reduction="none")
+    cost_mask = torch.matmul(pos / P, tm.T) + torch.matmul(neg / P, (1 - tm).T)
+    # pair-wise dice, HF:328-347
+    sig = pm.sigmoid()
+    num = 2 * torch.matmul(sig, tm.T)
+    den = sig.sum(-1)[:, None] + tm.sum(-1)[None, :]
+    cost_dice = 1 - (num + 1) / (den + 1)
+    cost = w_mask * cost_mask + w_class * cost_class + w_dice * cost_dice
+    cost = torch.minimum(cost, torch.tensor(1e10))
+    cost = torch.maximum(cost, torch.tensor(-1e10))
+    return torch.nan_to_num(cost, 0)
+
+
+def hungarian(cost):
+    """HF:474 (scipy on the host)."""
+    r, c = linear_sum_assignment(cost.detach().cpu().numpy())
+    return torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(c, dtype=torch.int64)
+
+
+# ----------------------------------------------------------------------------- loss (a7)
+def num_labels(cfg):
+    """config.json stores id2label, not num_labels."""
+    return int(num_labels(cfg)) if "num_labels" in cfg else len(cfg["id2label"])
+
+
+class RandSource:
+    """Stand-in for the global generator the dependency draws from (HF:455, HF:705, HF:721, HF:1905)."""
+
+    def __init__(self, draws=None):
+        self.draws = list(draws) if draws is not None else None
+        self.i = 0
+
+    def rand(self, *shape):
+        if self.draws is None:
+            return torch.rand(*shape)
+        d = self.draws[self.i]
+        self.i += 1
+        d = torch.as_tensor(d)
+        assert tuple(d.shape) == tuple(shape), (d.shape, shape)
+        return d
+
+
+def _criterion_level(masks, classes, mask_labels, class_labels, rs, cfg):
+    """One level of Mask2FormerLoss.forward, HF:726-769; returns (loss dict, indices)."""
+    B, Q = classes.shape[:2]
+    P = cfg["train_num_points"]
+    indices = []
+    for i in range(B):  # matcher, HF:444-475
+        pts = rs.rand(1, P, 2)
+        cost = matcher_cost(masks[i], classes[i], mask_labels[i], class_labels[i], pts,
+                            cfg["class_weight"], cfg["mask_weight"], cfg["dice_weight"])
+        indices.append(hungarian(cost))
+    num_masks = max(float(sum(len(c) for c in class_labels)), 1.0)  # HF:781-794, world size 1
+
+    # loss_masks, HF:580-640
+    bi = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)])
+    si = torch.cat([s for s, _ in indices])
+    pred = masks[bi, si][:, None]  # (M,1,h,w)
+    Ht = max(m.shape[1] for m in mask_labels)
+    Wt = max(m.shape[2] for m in mask_labels)
+    tgt = torch.cat([F.pad(m.to(masks.dtype), (0, Wt - m.shape[2], 0, Ht - m.shape[1]))[t]
+                     for m, (_, t) in zip(mask_labels, indices)])[:, None]
+    M = pred.shape[0]
+    n_over = int(P * cfg["oversample_ratio"])
+    n_unc = int(cfg["importance_sample_ratio"] * P)
+    with torch.no_grad():  # HF:671-724
+        pc = rs.rand(M, n_over, 2)
+        pl = sample_point(pred, pc)
+        unc = -pl.abs()
+        idx = torch.topk(unc[:, 0, :], k=n_unc, dim=1)[1]
+        pc_sel = torch.gather(pc, 1, idx[..., None].expand(-1, -1, 2))
+        if P - n_unc > 0:
+            pc_sel = torch.cat([pc_sel, rs.rand(M, P - n_unc, 2)], 1)
+        point_labels = sample_point(tgt, pc_sel).squeeze(1)
+    point_logits = sample_point(pred, pc_sel).squeeze(1)
+    bce = F.binary_cross_entropy_with_logits(point_logits, point_labels, reduction="none")
+    loss_mask = bce.mean(1).sum() / num_masks  # HF:308-324
+    probs = point_logits.sigmoid()
+    num = 2 * (probs * point_labels).sum(-1)
+    den = probs.sum(-1) + point_labels.sum(-1)
+    loss_dice = (1 - (num + 1) / (den + 1)).sum() / num_masks  # HF:278-305
+
+    # loss_labels, HF:546-578
+    target_classes = torch.full((B, Q), num_labels(cfg), dtype=torch.int64)
+    target_classes[bi, si] = torch.cat([c[t] for c, (_, t) in zip(class_labels, indices)])
+    ew = torch.ones(num_labels(cfg) + 1)
+    ew[-1] = cfg["no_object_weight"]
+    loss_ce = F.cross_entropy(classes.transpose(1, 2), target_classes, weight=ew)
+    return {"loss_mask": loss_mask, "loss_dice": loss_dice, "loss_cross_entropy": loss_ce}, indices
+
+
+def criterion(all_masks, all_classes, mask_labels, class_labels, rs, cfg):
+    """Mask2FormerLoss.forward + weighting, HF:726-779, HF:2301-2319.
+    all_masks / all_classes: per-level lists, LAST entry is the final prediction.  Draw order
+    follows the dependency: final level first, then auxiliary levels 0..n-2 (HF:762-777)."""
+    order = [len(all_masks) - 1] + list(range(len(all_masks) - 1))
+    wd = {"loss_cross_entropy": cfg["class_weight"], "loss_mask": cfg["mask_weight"], "loss_dice": cfg["dice_weight"]}
+    losses, indices_final = {}, None
+    for n, lvl in enumerate(order):
+        ld, idx = _criterion_level(all_masks[lvl], all_classes[lvl], mask_labels, class_labels, rs, cfg)
+        if n == 0:
+            indices_final = idx
+        suffix = "" if n == 0 else f"_{lvl}"
+        for k, v in ld.items():
+            losses[k + suffix] = v * wd[k]
+    return sum(losses.values()), losses, indices_final
+
+
+# ----------------------------------------------------------------------------- containers
+def sine_pos_embed(B, H, W, num_pos_feats, dtype=torch.float32, temperature=10000):
+    """HF:864-904 with normalize=True, scale=2*pi, no mask."""
+    scale, eps = 2 * math.pi, 1e-6
+    y = torch.arange(1, H + 1, dtype=dtype)[None, :, None].expand(B, H, W)
+    x = torch.arange(1, W + 1, dtype=dtype)[None, None, :].expand(B, H, W)
+    y = y / (y[:, -1:, :] + eps) * scale
+    x = x / (x[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.int64).to(dtype)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    px = x[:, :, :, None] / dim_t
+    py = y[:, :, :, None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
+
+
+def _bn(sd, p, x, eps=1e-5):
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, eps)
+
+
+def resnet_backbone(sd, prefix, x, cfg):
+    """transformers ResNetBackbone (bottleneck, v1.5 stride placement), eval mode."""
+    bc = cfg["backbone_config"]
+    p = prefix + "embedder.embedder."
+    x = F.relu(_bn(sd, p + "normalization.", F.conv2d(x, sd[p + "convolution.weight"], None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for s, depth in enumerate(bc["depths"]):
+        for j in range(depth):
+            lp = f"{prefix}encoder.stages.{s}.layers.{j}."
+            stride = 2 if (j == 0 and (s > 0 or bc.get("downsample_in_first_stage", False))) else 1
+            res = x
+            if lp + "shortcut.convolution.weight" in sd:
+                res = _bn(sd, lp + "shortcut.normalization.", F.conv2d(x, sd[lp + "shortcut.convolution.weight"], None, stride))
+            h = F.relu(_bn(sd, lp + "layer.0.normalization.", F.conv2d(x, sd[lp + "layer.0.convolution.weight"])))
+            h = F.relu(_bn(sd, lp + "layer.1.normalization.", F.conv2d(h, sd[lp + "layer.1.convolution.weight"], None, stride, 1)))
+            h = _bn(sd, lp + "layer.2.normalization.", F.conv2d(h, sd[lp + "layer.2.convolution.weight"]))
+            x = F.relu(h + res)
+        feats.append(x)
+    return feats
+
+
+def pixel_decoder(sd, prefix, feats, cfg):
+    """HF:1320-1419.  feats: 4 backbone maps, fine -> coarse.  Returns (mask_features, 3 multi-scale maps)."""
+    fs, nh = cfg["feature_size"], cfg["num_attention_heads"]
+    embeds, poss = [], []
+    for lvl, x in enumerate(feats[::-1][:3]):
+        p = f"{prefix}input_projections.{lvl}."
+        e = F.group_norm(F.conv2d(x, sd[p + "0.weight"], sd[p + "0.bias"]), 32, sd[p + "1.weight"], sd[p + "1.bias"])
+        embeds.append(e)
+        poss.append(sine_pos_embed(x.shape[0], x.shape[2], x.shape[3], fs // 2))
+    level_hw = [(e.shape[2], e.shape[3]) for e in embeds]
+    B = embeds[0].shape[0]
+    hidden = torch.cat([e.flatten(2).transpose(1, 2) for e in embeds], 1)
+    pos = torch.cat([p.flatten(2).transpose(1, 2) + sd[prefix + "level_embed"][i].view(1, 1, -1)
+                     for i, p in enumerate(poss)], 1)
+    ref = reference_points(level_hw, B)
+    for i in range(cfg["encoder_layers"]):  # HF:1036-1103
+        lp = f"{prefix}encoder.layers.{i}."
+        a, _ = msdeform_attn_module(sd, lp + "self_attn.", hidden, pos, ref, level_hw, nh)
+        hidden = F.layer_norm(hidden + a, (fs,), sd[lp + "self_attn_layer_norm.weight"], sd[lp + "self_attn_layer_norm.bias"])
+        f = F.linear(F.relu(F.linear(hidden, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])), sd[lp + "fc2.weight"], sd[lp + "fc2.bias"])
+        hidden = F.layer_norm(hidden + f, (fs,), sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"])
+    outs, start = [], 0
+    for hh, ww in level_hw:
+        outs.append(hidden[:, start:start + hh * ww].transpose(1, 2).reshape(B, fs, hh, ww))
+        start += hh * ww
+    # FPN: strides down to common_stride, HF:1292-1318, HF:1395-1405
+    n_fpn = int(np.log2(min(cfg["feature_strides"][-3:])) - np.log2(cfg["common_stride"]))
+    for idx, feat in enumerate(feats[:n_fpn][::-1]):
+        k = n_fpn - idx  # adapter_k / layer_k were created in fine->coarse order, applied coarse->fine
+        lat = F.group_norm(F.conv2d(feat, sd[f"{prefix}adapter_{k}.0.weight"]), 32,
+                           sd[f"{prefix}adapter_{k}.1.weight"], sd[f"{prefix}adapter_{k}.1.bias"])
+        out = lat + F.interpolate(outs[-1], size=lat.shape[-2:], mode="bilinear", align_corners=False)
+        out = F.relu(F.group_norm(F.conv2d(out, sd[f"{prefix}layer_{k}.0.weight"], None, 1, 1), 32,
+                                  sd[f"{prefix}layer_{k}.1.weight"], sd[f"{prefix}layer_{k}.1.bias"]))
+        outs.append(out)
+    mask_features = F.conv2d(outs[-1], sd[prefix + "mask_projection.weight"], sd[prefix + "mask_projection.bias"])
+    return mask_features, outs[:3]
+
+
+def _self_attention(sd, p, h, qpos, nh):
+    """Mask2FormerAttention, HF:1451-1584; h, qpos (Q,B,E) sequence-first."""
+    Q, B, E = h.shape
+    D = E // nh
+    hb, pb = h.permute(1, 0, 2), qpos.permute(1, 0, 2)
+    hq = hb + pb
+    q = F.linear(hq, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * (D ** -0.5)
+    k = F.linear(hq, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(hb, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    sh = lambda t: t.view(B, Q, nh, D).transpose(1, 2)
+    a = torch.softmax(torch.matmul(sh(q), sh(k).transpose(-1, -2)), -1)
+    o = torch.matmul(a, sh(v)).transpose(1, 2).reshape(B, Q, E)
+    return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"]).permute(1, 0, 2)
+
+
+def transformer_module(sd, prefix, multi_scale, mask_features, cfg):
+    """HF:2059-2129 + HF:1801-1960 (post-norm layers, eval: no layer drop)."""
+    hd, nh = cfg["hidden_dim"], cfg["num_attention_heads"]
+    B = mask_features.shape[0]
+    feats, poss, sizes = [], [], []
+    for i in range(3):
+        f = multi_scale[i]
+        sizes.append(tuple(f.shape[-2:]))
+        poss.append(sine_pos_embed(B, f.shape[2], f.shape[3], hd // 2).flatten(2).permute(2, 0, 1))
+        # input_projections are identity when feature_size == hidden_dim (HF:2075-2079)
+        feats.append((f.flatten(2) + sd[prefix + "level_embed.weight"][i][None, :, None]).permute(2, 0, 1))
+    qpos = sd[prefix + "queries_embedder.weight"].unsqueeze(1).repeat(1, B, 1)
+    h = sd[prefix + "queries_features.weight"].unsqueeze(1).repeat(1, B, 1)
+    dp = prefix + "decoder."
+    ln = lambda t: F.layer_norm(t, (hd,), sd[dp + "layernorm.weight"], sd[dp + "layernorm.bias"])
+    inter = [ln(h)]
+    logits, amask = mask_predictor(sd, dp + "mask_predictor.", inter[0], mask_features, sizes[0])
+    all_masks = [logits]
+    for idx in range(cfg["decoder_layers"] - 1):
+        lvl = idx % 3
+        lp = f"{dp}layers.{idx}."
+        a = masked_cross_attention(sd, lp + "cross_attn.", h + qpos, feats[lvl] + poss[lvl], feats[lvl], amask, nh)
+        h = F.layer_norm(h + a, (hd,), sd[lp + "cross_attn_layer_norm.weight"], sd[lp + "cross_attn_layer_norm.bias"])
+        a = _self_attention(sd, lp + "self_attn.", h, qpos, nh)
+        h = F.layer_norm(h + a, (hd,), sd[lp + "self_attn_layer_norm.weight"], sd[lp + "self_attn_layer_norm.bias"])
+        f = F.linear(F.relu(F.linear(h, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])), sd[lp + "fc2.weight"], sd[lp + "fc2.bias"])
+        h = F.layer_norm(h + f, (hd,), sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"])
+        inter.append(ln(h))
+        logits, amask = mask_predictor(sd, dp + "mask_predictor.", inter[-1], mask_features, sizes[(idx + 1) % 3])
+        all_masks.append(logits)
+    return inter, all_masks
+
+
+def forward(sd, cfg, pixel_values, mask_labels=None, class_labels=None, rand_source=None, backbone_feats=None):
+    """Mask2FormerForUniversalSegmentation.forward, HF:2332-2530, eval mode.
+
+    sd: state dict with the dependency's names.  cfg: its config as a dict.
+    Returns dict(masks_queries_logits, class_queries_logits, aux_masks, aux_classes, loss, loss_dict, indices,
+    mask_features, multi_scale, backbone)."""
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
+    with torch.no_grad():
+        rs = rand_source or RandSource()
+        for _ in range(cfg["decoder_layers"] - 1):
+            pass  # the dependency draws rand([]) per decoder layer (HF:1905); replay lists strip them beforehand
+        feats = backbone_feats
+        if feats is None:
+            if cfg["backbone_config"]["model_type"] != "resnet":
+                raise NotImplementedError("oracle backbone: resnet only")
+            feats = resnet_backbone(sd, "model.pixel_level_module.encoder.", pixel_values, cfg)
+        mask_features, multi_scale = pixel_decoder(sd, "model.pixel_level_module.decoder.", feats, cfg)
+        inter, all_masks = transformer_module(sd, "model.transformer_module.", multi_scale, mask_features, cfg)
+        all_classes = [F.linear(s.transpose(0, 1), sd["class_predictor.weight"], sd["class_predictor.bias"]) for s in inter]
+        res = dict(masks_queries_logits=all_masks[-1], class_queries_logits=all_classes[-1], aux_masks=all_masks[:-1],
+                   aux_classes=all_classes[:-1], mask_features=mask_features, multi_scale=multi_scale, backbone=feats,
+                   loss=None, loss_dict=None, indices=None)
+        if mask_labels is not None and class_labels is not None:
+            loss, ld, idx = criterion(all_masks, all_classes, mask_labels, class_labels, rs, cfg)
+            res.update(loss=loss, loss_dict=ld, indices=idx)
+        return res
