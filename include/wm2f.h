@@ -1,0 +1,139 @@
+/*
+ * wm2f.h -- C ABI of libwm2f.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * Mask2Former hot path of marco-conciatori-public/weed_instance_segmentation.
+ *
+ * The reference has no FFI for this path: it calls the Python package `transformers`
+ * (train.py:196, metrics.py:56, inference.py:27).  Each entry point below therefore
+ * cites the Python function of that dependency whose arithmetic it replaces
+ * ("HF:n" = transformers/models/mask2former/modeling_mask2former.py line n,
+ *  "TORCHF:n" = torch/nn/functional.py line n, transformers 5.15.0 / torch 2.10).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless marked "host";
+ *     tensors are contiguous, row-major, in the shape written next to them;
+ *   - nothing is allocated, freed or retained; there is no global mutable state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no hidden syncs;
+ *   - return 0 on success, a negative WM2F_E* code otherwise; wm2f_last_error() gives the
+ *     thread-local message of the last failing call on this thread;
+ *   - dtype: WM2F_F32 = 0 (fp32 storage + fp32 arithmetic). WM2F_BF16 = 1 is reserved.
+ */
+#ifndef WM2F_H
+#define WM2F_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM2F_VERSION 100 /* 0.1.0 */
+
+#define WM2F_F32 0
+#define WM2F_BF16 1
+
+#define WM2F_OK 0
+#define WM2F_EINVAL (-1)      /* bad argument / unsupported shape */
+#define WM2F_EUNSUPPORTED (-2) /* dtype or configuration not built */
+#define WM2F_ELAUNCH (-3)     /* hipLaunch / runtime error */
+
+#define WM2F_MAX_LEVELS 8
+
+int wm2f_version(void);
+const char* wm2f_last_error(void);
+
+/* ---- K1: multi-scale deformable attention core ------------------------------------------
+ * Replaces multi_scale_deformable_attention(), HF:798-837.
+ *   value   (B, S, heads, D)        S = sum_l H_l*W_l, levels stored back to back
+ *   loc     (B, Q, heads, L, P, 2)  normalised (x, y); pixel = loc * (W_l, H_l) - 0.5
+ *   attn_w  (B, Q, heads, L, P)
+ *   out     (B, Q, heads*D)
+ *   level_hw  host int32 [L][2] = (H_l, W_l)
+ * Bilinear, zero padding, align_corners = False.  D in {8, 16, 32, 64}.
+ */
+int wm2f_msdeform_fwd(const void* value, const void* loc, const void* attn_w, void* out,
+                      const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
+                      int dtype, void* stream);
+
+/* Backward of the above.  grad_value (B,S,heads,D) must be ZEROED by the caller (it is
+ * accumulated with float atomics); grad_loc, grad_attn_w are overwritten. */
+int wm2f_msdeform_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out,
+                      void* grad_value, void* grad_loc, void* grad_attn_w,
+                      const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
+                      int dtype, void* stream);
+
+/* K1 with the module prologue fused (HF:983-1002): softmax over the L*P logits and
+ * loc = ref + offset / (W_l, H_l) are computed in-kernel.
+ *   offsets (B, Q, heads, L, P, 2)  raw sampling_offsets output
+ *   logits  (B, Q, heads, L*P)      raw attention_weights output (pre-softmax)
+ *   ref     (Q, L, 2)               reference points, shared by the batch (valid ratios are 1)
+ */
+int wm2f_msdeform_fused_fwd(const void* value, const void* offsets, const void* logits, const void* ref,
+                            void* out, const int32_t* level_hw, int B, int S, int Q, int heads, int D,
+                            int L, int P, int dtype, void* stream);
+
+/* ---- K3: mask einsum --------------------------------------------------------------------
+ * Replaces torch.einsum("bqc,bchw->bqhw"), HF:2046.
+ *   emb (B, Q, C)   pix (B, C, HW)   out (B, Q, HW)      C % 16 == 0
+ */
+int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out, int B, int Q, int C, int HW,
+                         int dtype, void* stream);
+
+/* ---- attention-mask build ----------------------------------------------------------------
+ * Replaces HF:2048-2054 (bilinear resize, sigmoid, < 0.5) WITHOUT the x num_heads replication,
+ * and the row fix-up of HF:1912-1914.
+ *   logits   (B, Q, H, W) fp32
+ *   mask     (B, Q, Hn*Wn) uint8, 1 = blocked
+ *   row_open (B, Q) int32, 1 if at least one key of the row is open (0 => attend everywhere)
+ */
+int wm2f_attn_mask_build(const void* logits, void* mask, void* row_open, int B, int Q, int H, int W,
+                         int Hn, int Wn, void* stream);
+
+/* ---- K2: masked cross-attention ------------------------------------------------------------
+ * Replaces the attention arithmetic of nn.MultiheadAttention as called at HF:1644-1650
+ * (TORCHF:6578-6600): softmax(bias + (q/sqrt(D)) k^T) v, bias = -inf where mask == 1; rows with
+ * row_open == 0 ignore the mask (HF:1912-1914).  Projections stay outside.
+ *   q (B, Q, heads*D) ALREADY scaled by 1/sqrt(D);  k, v (B, N, heads*D)
+ *   mask (B, Q, N) uint8 shared by all heads, or NULL;  row_open (B, Q) int32 or NULL
+ *   out (B, Q, heads*D);  lse (B, heads, Q) fp32 log-sum-exp per row (for backward) or NULL
+ *   workspace: device scratch of at least wm2f_masked_xattn_workspace(...) bytes
+ * D in {16, 32, 64}.
+ */
+int64_t wm2f_masked_xattn_workspace(int B, int heads, int Q, int N, int D);
+int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v, const void* mask,
+                          const void* row_open, void* out, void* lse, void* workspace,
+                          int B, int heads, int Q, int N, int D, int dtype, void* stream);
+
+/* ---- K4: Hungarian-matcher cost matrices ------------------------------------------------------
+ * Replaces Mask2FormerHungarianMatcher.forward up to (not including) the scipy solver,
+ * HF:444-472 with sample_point HF:245-274 and the pair-wise losses HF:328-374, batched over
+ * NL prediction levels and B images so that ONE device->host copy feeds every solver call.
+ *   mask_logits  (NL, B, Q, h, w) fp32           class_logits (NL, B, Q, C1) fp32
+ *   tgt_masks    concatenation over images of (T_i, Ht, Wt); tgt_dtype 0 = fp32, 1 = uint8
+ *   tgt_offset   host int32 [B+1]: image i owns targets [tgt_offset[i], tgt_offset[i+1])
+ *   tgt_classes  int64 [sum T_i]
+ *   points       (NL, B, P, 2) fp32 in [0,1] as (x, y)
+ *   cost         (NL, B, Q, Tmax) fp32; columns >= T_i are left untouched
+ *   workspace    fp32 scratch, at least wm2f_matcher_workspace(...) bytes
+ * cost = w_mask*BCE_pair + w_class*(-softmax(class)[:, tgt]) + w_dice*dice_pair, clamped to
+ * +-1e10 with NaN -> 0.
+ */
+int64_t wm2f_matcher_workspace(int NL, int B, int Q, int P, int Tsum);
+int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const void* tgt_masks,
+                      int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes,
+                      const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1,
+                      int h, int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask,
+                      float w_dice, void* stream);
+
+/* ---- point sampling (shared by the loss, HF:245-274) ----------------------------------------
+ *   feat (N, H, W) fp32 or uint8 (feat_dtype 0 / 1); pts (N, P, 2); out (N, P) fp32.
+ * Backward (fp32 feat only): grad_feat (N,H,W) must be zeroed by the caller. */
+int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, void* out, int N, int H,
+                          int W, int P, void* stream);
+int wm2f_point_sample_bwd(const void* grad_out, const void* pts, void* grad_feat, int N, int H, int W,
+                          int P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM2F_H */

@@ -1,0 +1,236 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle and the golden vectors.
+Needs a real MI355X:  python -m pytest tests -m gpu
+
+Tolerances: fp32 results within 1e-3 relative of the oracle (BASELINE.json north_star); in practice
+the kernels sit at 1e-5..1e-6, and the tests hold them to that.  Index outputs are bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import m2f_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from weed_instance_segmentation_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ----------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("tag", ["toy", "rect", "d8"])
+def test_k1_golden(ops, tag):
+    g = load_golden(f"k1_msdeform_{tag}.npz")
+    out = ops.ms_deform_attn(dev(T(g["value"])), g["level_hw"].tolist(), dev(T(g["loc"])), dev(T(g["w"])))
+    torch.testing.assert_close(out.cpu(), T(g["out"]), rtol=1e-5, atol=2e-6)
+
+
+def _rand_k1(B, shapes, H, D, seed, spread=1.2):
+    g = torch.Generator().manual_seed(seed)
+    S = sum(h * w for h, w in shapes)
+    L, P = len(shapes), 4
+    value = torch.randn(B, S, H, D, generator=g)
+    loc = torch.rand(B, S, H, L, P, 2, generator=g) * spread - (spread - 1) / 2
+    w = torch.softmax(torch.randn(B, S, H, L * P, generator=g), -1).view(B, S, H, L, P)
+    return value, loc, w
+
+
+@pytest.mark.parametrize("shapes,B,H,D", [([(8, 8), (16, 16), (32, 32)], 2, 8, 32),
+                                          ([(5, 7), (10, 14), (20, 28)], 3, 8, 32),
+                                          ([(4, 4), (8, 8)], 1, 4, 16),
+                                          ([(6, 6)], 2, 2, 64)])
+def test_k1_random_vs_oracle(ops, shapes, B, H, D):
+    value, loc, w = _rand_k1(B, shapes, H, D, 1)
+    ref = O.msdeform_attn_core(value, shapes, loc, w)
+    out = ops.ms_deform_attn(dev(value), shapes, dev(loc), dev(w))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=5e-6)
+
+
+def test_k1_fused_prologue(ops):
+    shapes = [(8, 8), (16, 16), (32, 32)]
+    B, H, D, L, P = 2, 8, 32, 3, 4
+    g = torch.Generator().manual_seed(2)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * 3
+    logits = torch.randn(B, S, H, L * P, generator=g) * 2
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()  # (S, L, 2)
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw = torch.softmax(logits, -1).view(B, S, H, L, P)
+    ref = O.msdeform_attn_core(value, shapes, loc, aw)
+    out = ops.ms_deform_attn_fused(dev(value), shapes, dev(off), dev(logits), dev(ref_pts))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_k1_backward(ops):
+    shapes = [(4, 6), (8, 12), (16, 24)]
+    value, loc, w = _rand_k1(2, shapes, 8, 32, 3, spread=1.1)
+    go = torch.randn(2, value.shape[1], 8 * 32, generator=torch.Generator().manual_seed(4))
+    v0, l0, w0 = value.clone().requires_grad_(), loc.clone().requires_grad_(), w.clone().requires_grad_()
+    O.msdeform_attn_core(v0, shapes, l0, w0).backward(go)
+    v1, l1, w1 = dev(value).requires_grad_(), dev(loc).requires_grad_(), dev(w).requires_grad_()
+    ops.ms_deform_attn(v1, shapes, l1, w1).backward(dev(go))
+    torch.testing.assert_close(v1.grad.cpu(), v0.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(w1.grad.cpu(), w0.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(l1.grad.cpu(), l0.grad, rtol=1e-3, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- K3
+def test_k3_golden(ops):
+    g = load_golden("k3_mask_predictor.npz")
+    out = ops.mask_einsum(dev(T(g["mask_embeddings"])), dev(T(g["pix"])))
+    torch.testing.assert_close(out.cpu(), T(g["logits"]), rtol=1e-4, atol=1e-4)
+    for i in range(5):
+        m, ro = ops.attn_mask_build(dev(T(g["logits"])), g[f"size_{i}"])
+        exp = T(g[f"attn_mask_{i}"])
+        mism = (m.cpu().bool() != exp).float().mean().item()
+        assert mism <= 1e-5, f"size {g[f'size_{i}']}: {mism}"
+        assert torch.equal(ro.cpu().bool(), ~exp.all(-1))
+
+
+@pytest.mark.parametrize("B,Q,C,H,W", [(2, 100, 256, 64, 64), (1, 200, 256, 32, 48), (2, 10, 64, 16, 24),
+                                       (1, 37, 128, 20, 36), (1, 100, 256, 3, 12)])
+def test_k3_random(ops, B, Q, C, H, W):
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(B, Q, C, generator=g)
+    pix = torch.randn(B, C, H, W, generator=g)
+    ref = torch.einsum("bqc,bchw->bqhw", emb.double(), pix.double())
+    out = ops.mask_einsum(dev(emb), dev(pix)).cpu()
+    scale = ref.abs().max().item()
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * scale * math.sqrt(C)
+    # exact-integer data pins the fragment layout (a swapped row/col map cannot pass)
+    emb_i = torch.randint(-3, 4, (B, Q, C), generator=g).float()
+    pix_i = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
+    assert torch.equal(ops.mask_einsum(dev(emb_i), dev(pix_i)).cpu(), torch.einsum("bqc,bchw->bqhw", emb_i, pix_i))
+
+
+def test_k3_backward(ops):
+    g = torch.Generator().manual_seed(6)
+    emb, pix = torch.randn(2, 20, 64, generator=g), torch.randn(2, 64, 8, 12, generator=g)
+    go = torch.randn(2, 20, 8, 12, generator=g)
+    e0, p0 = emb.clone().requires_grad_(), pix.clone().requires_grad_()
+    torch.einsum("bqc,bchw->bqhw", e0, p0).backward(go)
+    e1, p1 = dev(emb).requires_grad_(), dev(pix).requires_grad_()
+    ops.mask_einsum(e1, p1).backward(dev(go))
+    torch.testing.assert_close(e1.grad.cpu(), e0.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(p1.grad.cpu(), p0.grad, rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize("tag", ["small", "q100"])
+def test_k2_golden(ops, tag):
+    g = load_golden(f"k2_masked_xattn_{tag}.npz")
+    H = int(g["n_heads"])
+    q, k, v = T(g["q_proj"]), T(g["k_proj"]), T(g["v_proj"])  # (Q|N, B, E)
+    E = q.shape[-1]
+    D = E // H
+    mask = T(g["mask"])
+    qb = (q.transpose(0, 1) * (1.0 / math.sqrt(D))).contiguous()
+    kb, vb = k.transpose(0, 1).contiguous(), v.transpose(0, 1).contiguous()
+    row_open = (~mask.all(-1)).to(torch.int32)
+    ctx = ops.masked_xattn(dev(qb), dev(kb), dev(vb), dev(mask.to(torch.uint8)), dev(row_open), H)  # (B,Q,E)
+    out = torch.nn.functional.linear(ctx.cpu(), T(g["out_proj_weight"]), T(g["out_proj_bias"])).transpose(0, 1)
+    torch.testing.assert_close(out, T(g["out"]), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,H,Q,N,D,use_mask", [(2, 8, 100, 1024, 32, True), (1, 8, 100, 1000, 32, True),
+                                                (2, 2, 10, 37, 32, True), (1, 4, 200, 256, 32, True),
+                                                (2, 8, 100, 512, 32, False), (1, 2, 50, 300, 64, True),
+                                                (1, 4, 20, 130, 16, True)])
+def test_k2_random(ops, B, H, Q, N, D, use_mask):
+    g = torch.Generator().manual_seed(7)
+    E = H * D
+    q = torch.randn(B, Q, E, generator=g) * 0.5
+    k = torch.randn(B, N, E, generator=g)
+    v = torch.randn(B, N, E, generator=g)
+    mask = torch.rand(B, Q, N, generator=g) < 0.7
+    mask[0, 0] = True  # fully blocked row -> attends everywhere
+    mask[0, 1, :-1] = True
+    mask[0, 1, -1] = False
+    sh = lambda t, n: t.view(B, n, H, D).permute(0, 2, 1, 3)
+    ref = O.masked_attention_core(sh(q, Q), sh(k, N), sh(v, N), mask if use_mask else torch.zeros_like(mask))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Q, E)
+    if use_mask:
+        ro = (~mask.all(-1)).to(torch.int32)
+        out = ops.masked_xattn(dev(q), dev(k), dev(v), dev(mask.to(torch.uint8)), dev(ro), H)
+    else:
+        out = ops.masked_xattn(dev(q), dev(k), dev(v), None, None, H)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------- K4
+def test_k4_golden_cost_and_indices(ops):
+    g = load_golden("k4_matcher.npz")
+    wc, wm, wd = [float(x) for x in g["weights"]]
+    B = g["mask_logits"].shape[0]
+    counts = [g[f"mask_labels_{i}"].shape[0] for i in range(B)]
+    for tgt_dtype in (torch.float32, torch.uint8):
+        tgt = torch.cat([T(g[f"mask_labels_{i}"]) for i in range(B)]).to(tgt_dtype)
+        cls = torch.cat([T(g[f"class_labels_{i}"]) for i in range(B)])
+        cost = ops.matcher_cost(dev(T(g["mask_logits"])[None]), dev(T(g["class_logits"])[None]), dev(tgt), counts,
+                                dev(cls), dev(T(g["points"])[None]), wc, wm, wd)[0].cpu()
+        for i in range(B):
+            c = cost[i, :, :counts[i]]
+            torch.testing.assert_close(c, T(g[f"cost_{i}"]), rtol=1e-5, atol=1e-5)
+            r, col = O.hungarian(c)
+            assert np.array_equal(r.numpy(), g[f"row_{i}"]) and np.array_equal(col.numpy(), g[f"col_{i}"])
+
+
+def test_k4_multi_level_ragged(ops):
+    g = torch.Generator().manual_seed(8)
+    NL, B, Q, h, w, Ht, Wt, P, C1 = 3, 3, 25, 16, 20, 64, 80, 500, 4
+    ml = torch.randn(NL, B, Q, h, w, generator=g) * 2
+    cl = torch.randn(NL, B, Q, C1, generator=g)
+    counts = [11, 0, 3]
+    tgt = (torch.rand(sum(counts), Ht, Wt, generator=g) < 0.3).float()
+    cls = torch.randint(0, C1 - 1, (sum(counts),), generator=g)
+    pts = torch.rand(NL, B, P, 2, generator=g)
+    cost = ops.matcher_cost(dev(ml), dev(cl), dev(tgt), counts, dev(cls), dev(pts), 2.0, 5.0, 5.0).cpu()
+    off = 0
+    for b in range(B):
+        for lvl in range(NL):
+            if counts[b]:
+                ref = O.matcher_cost(ml[lvl, b], cl[lvl, b], tgt[off:off + counts[b]], cls[off:off + counts[b]],
+                                     pts[lvl, b:b + 1], 2.0, 5.0, 5.0)
+                torch.testing.assert_close(cost[lvl, b, :, :counts[b]], ref, rtol=1e-5, atol=1e-5)
+        off += counts[b]
+
+
+# ----------------------------------------------------------------------------------------- point sampling
+def test_point_sample_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(9)
+    N, H, W, P = 5, 12, 17, 300
+    feat = torch.randn(N, H, W, generator=g)
+    pts = torch.rand(N, P, 2, generator=g) * 1.2 - 0.1
+    go = torch.randn(N, P, generator=g)
+    f0 = feat.clone().requires_grad_()
+    ref = torch.nn.functional.grid_sample(f0[:, None], 2 * pts[:, :, None] - 1, align_corners=False)[:, 0, :, 0]
+    ref.backward(go)
+    f1 = dev(feat).requires_grad_()
+    out = ops.point_sample(f1, dev(pts))
+    out.backward(dev(go))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(f1.grad.cpu(), f0.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.detach().cpu(), O.sample_point(feat[:, None], pts)[:, 0], rtol=1e-5, atol=1e-6)
+    u8 = (feat > 0).to(torch.uint8)
+    out8 = ops.point_sample(dev(u8), dev(pts)).cpu()
+    torch.testing.assert_close(out8, O.sample_point(u8[:, None].float(), pts)[:, 0], rtol=1e-5, atol=1e-6)
+
+
+def test_cpu_tensor_is_refused(ops):
+    from weed_instance_segmentation_amd._lib import Wm2fError
+    with pytest.raises(Wm2fError):
+        ops.mask_einsum(torch.randn(1, 4, 16), torch.randn(1, 16, 2, 2))

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at the config-2 shapes (1024x1024, B=8, R50, Q=100, fp32) with HIP events.
+Usage: python tools/kbench.py [--iters 20] [--only k1,k3,k2,mask,k4]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from weed_instance_segmentation_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)  # us
+    return dict(min_us=ts[0], med_us=ts[len(ts) // 2], mean_us=sum(ts) / len(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="k1,k1f,k3,mask,k2,k4")
+    ap.add_argument("--B", type=int, default=8)
+    a = ap.parse_args()
+    only = set(a.only.split(","))
+    dev = torch.device("cuda:0")
+    B, H, D, L, P, Q = a.B, 8, 32, 3, 4, 100
+    shapes = [(32, 32), (64, 64), (128, 128)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    res = {}
+    if "k1" in only or "k1f" in only:
+        value = torch.randn(B, S, H, D, device=dev)
+        # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
+                         for h, w in shapes]).to(dev)  # (S,2) x,y
+        off = (torch.randn(B, S, H, L, P, 2, device=dev) * 2.0)
+        norm = torch.tensor([[w, h] for h, w in shapes], device=dev, dtype=torch.float32)
+        loc = (ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+        logits = torch.randn(B, S, H, L * P, device=dev)
+        aw = torch.softmax(logits, -1).view(B, S, H, L, P).contiguous()
+        nbytes = 4 * (value.numel() + loc.numel() + aw.numel() + value.numel())
+        if "k1" in only:
+            r = timeit(lambda: ops.ms_deform_attn(value, shapes, loc, aw), a.iters)
+            r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
+            res["k1_msdeform_fwd"] = r
+        if "k1f" in only:
+            refl = ref[:, None, :].expand(S, L, 2).contiguous()
+            r = timeit(lambda: ops.ms_deform_attn_fused(value, shapes, off, logits, refl), a.iters)
+            r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
+            res["k1_msdeform_fused_fwd"] = r
+    if "k3" in only or "mask" in only:
+        emb = torch.randn(B, Q, 256, device=dev)
+        pix = torch.randn(B, 256, 256, 256, device=dev)
+        flop = 2 * B * Q * 256 * 65536
+        if "k3" in only:
+            r = timeit(lambda: ops.mask_einsum(emb, pix), a.iters)
+            r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6, bytes=4 * (emb.numel() + pix.numel() + B * Q * 65536))
+            res["k3_mask_einsum_fwd"] = r
+            r2 = timeit(lambda: torch.einsum("bqc,bchw->bqhw", emb, pix), a.iters)
+            r2.update(TFLOPs=flop / r2["med_us"] / 1e6)
+            res["k3_torch_einsum_ref"] = r2
+        if "mask" in only:
+            logits = ops.mask_einsum(emb, pix)
+            for hw in shapes:
+                res[f"attn_mask_build_{hw[0]}"] = timeit(lambda: ops.attn_mask_build(logits, hw), a.iters)
+    if "k2" in only:
+        E = H * D
+        q = torch.randn(B, Q, E, device=dev) * 0.3
+        for hw in shapes:
+            N = hw[0] * hw[1]
+            k = torch.randn(B, N, E, device=dev)
+            v = torch.randn(B, N, E, device=dev)
+            mask = (torch.rand(B, Q, N, device=dev) < 0.5).to(torch.uint8)
+            ro = torch.ones(B, Q, device=dev, dtype=torch.int32)
+            r = timeit(lambda: ops.masked_xattn(q, k, v, mask, ro, H), a.iters)
+            flop = 4 * B * H * Q * N * D
+            r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6, kv_bytes=2 * B * N * E * 4)
+            res[f"k2_masked_xattn_N{N}"] = r
+    if "k4" in only:
+        NL, Tn, Pn = 10, 16, 12544
+        ml = torch.randn(NL, B, Q, 256, 256, device=dev)
+        cl = torch.randn(NL, B, Q, 4, device=dev)
+        tgt = (torch.rand(B * Tn, 1024, 1024, device=dev) < 0.1).float()
+        cls = torch.randint(0, 3, (B * Tn,), device=dev)
+        pts = torch.rand(NL, B, Pn, 2, device=dev)
+        res["k4_matcher_cost_all_levels_f32tgt"] = timeit(lambda: ops.matcher_cost(ml, cl, tgt, [Tn] * B, cls, pts, 2., 5., 5.), max(3, a.iters // 4))
+        tgt8 = tgt.to(torch.uint8)
+        res["k4_matcher_cost_all_levels_u8tgt"] = timeit(lambda: ops.matcher_cost(ml, cl, tgt8, [Tn] * B, cls, pts, 2., 5., 5.), max(3, a.iters // 4))
+    for k, v in res.items():
+        print(json.dumps({"kernel": k, **{kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""ctypes binding of libwm2f.so (C ABI declared in include/wm2f.h).
+
+There is NO fallback: if the library is missing or a call fails, the op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwm2f.so")
+
+WM2F_F32 = 0
+WM2F_BF16 = 1
+
+_P = c_void_p
+_I = c_int
+_HOST_I32 = POINTER(c_int32)
+
+# name -> (restype, argtypes); mirrors include/wm2f.h one to one
+SIGNATURES = {
+    "wm2f_version": (c_int, []),
+    "wm2f_last_error": (c_char_p, []),
+    "wm2f_msdeform_fwd": (c_int, [_P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_msdeform_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_msdeform_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_mask_einsum_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_masked_xattn_workspace": (c_int64, [_I, _I, _I, _I, _I]),
+    "wm2f_masked_xattn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_matcher_workspace": (c_int64, [_I, _I, _I, _I, _I]),
+    "wm2f_matcher_cost": (c_int, [_P, _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                  c_float, c_float, c_float, _P]),
+    "wm2f_point_sample_fwd": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "wm2f_point_sample_bwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class Wm2fError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libwm2f.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Wm2fError(
+                f"{LIB_PATH} not found: build it with `python -m weed_instance_segmentation_amd._build` "
+                "(hipcc, gfx950). There is no CPU or PyTorch fallback for the hot path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().wm2f_last_error()
+        raise Wm2fError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def host_i32(values) -> ctypes.Array:
+    flat = [int(v) for v in values]
+    return (c_int32 * len(flat))(*flat)

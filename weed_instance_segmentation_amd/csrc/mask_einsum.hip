@@ -1,0 +1,182 @@
+// K3: per-query mask-embedding x pixel-feature contraction on the fp32 matrix cores.
+// Replaces torch.einsum("bqc,bchw->bqhw"), transformers modeling_mask2former.py:2046.
+//
+//   emb (B, Q, C)   pix (B, C, HW)   out (B, Q, HW)          all fp32, row-major
+//
+// MFMA shape: v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles/SIMD).  Q = 100 pads to 7 row tiles
+// (112) instead of the 128 a 32x32 tile would need.
+//
+// One wave owns a strip of 64 consecutive pixels (4 column tiles) and ALL query row tiles:
+//   - B operand (pix) goes HBM -> registers directly, each element read exactly once by exactly
+//     one wave: a lane loads float4 pix[c][p0+4*(lane&15) ..+3]; component j feeds column tile j,
+//     so a wave-load is 4 channel rows x 256 contiguous bytes and the 4 column tiles of a lane
+//     are 4 consecutive pixels -> the epilogue stores float4 rows.
+//   - A operand (emb, <= 112 KiB) is staged once per workgroup into LDS in FRAGMENT order
+//     [row tile][k super-step][lane][4], so the main loop's ds_read_b128 is lane-linear
+//     (conflict-free) and yields the A values of 4 consecutive k-steps.
+//   - k order: super-step s covers channels 16s..16s+15; lane group g = lane>>4 takes channels
+//     16s+4g+t at k-step t.  Summation order is a fixed permutation of ascending channel order.
+//
+// Roofline (fp32): MFMA.  2*B*Q*C*HW flop per call (26.84 GFLOP at config 2) against
+// 157.3 TFLOP/s; the Q=100 -> 112 padding caps useful MFMA work at 89 %.  HBM side:
+// 4*(B*C*HW + B*Q*HW + B*Q*C) bytes, each read / written once.
+#include "common.h"
+
+namespace wm2f {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+constexpr int kStripPix = 64;   // pixels per wave strip (4 column tiles x 16)
+constexpr int kEinsumWaves = 8; // waves per workgroup (2 per SIMD)
+
+template <int MT>
+__global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(const float* __restrict__ emb,
+                                                                              const float* __restrict__ pix,
+                                                                              float* __restrict__ out, int Q, int C,
+                                                                              int HW, int q_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float e_lds[];  // [MT][C/16][64][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y / q_chunks, chunk = blockIdx.y % q_chunks;
+  const int q0 = chunk * (MT * 16);
+  const int S16 = C / 16, C4 = C / 4;
+
+  // ---- stage emb rows q0 .. q0+16*MT-1 into LDS, fragment order, zero rows beyond Q
+  const float* eb = emb + (int64_t)b * Q * C;
+  for (int idx = tid; idx < MT * 16 * C4; idx += kEinsumWaves * kWave) {
+    const int r = idx / C4, c4 = idx - r * C4;
+    const int col = c4 * 4, s = col >> 4, g = (col & 15) >> 2;
+    const int mt = r >> 4, m = r & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)(q0 + r) * C + col);
+    *reinterpret_cast<float4*>(e_lds + ((int64_t)(mt * S16 + s) * 64 + (g * 16 + m)) * 4) = v;
+  }
+  __syncthreads();
+
+  const int strip = blockIdx.x * kEinsumWaves + wave;
+  const int n_strips = ceil_div(HW, kStripPix);
+  if (strip >= n_strips) return;  // whole wave leaves together; no barrier follows
+
+  const int g = lane >> 4;
+  const int p0 = strip * kStripPix + 4 * (lane & 15);
+  const bool pvalid = p0 < HW;  // HW % 4 == 0 is checked on the host
+  // Buffer descriptors: per-lane byte offset in ONE VGPR (constant over the loop), the row of
+  // each k-step as a scalar offset, and the hardware range check drops the strip / row tails
+  // (out-of-range loads return 0, out-of-range stores are discarded).
+  const uint32_t kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t pix_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(pix + (int64_t)b * C * HW), 0, C * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(out + (int64_t)b * Q * HW), 0, Q * HW * 4, 0x00020000);
+  const uint32_t voff = pvalid ? (uint32_t)((4 * g * HW + p0) * 4) : kOob;
+  const int row_bytes = HW * 4;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Two named register sets (b0 / b1) and a 2x unrolled loop: the loads of super-step s+1 are
+  // issued before the MFMAs of super-step s and waited for with a COUNTED vmcnt only when used.
+  f32x4 b0[4], b1[4];
+  auto load_b = [&](f32x4 (&dst)[4], int s) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      dst[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pix_rsrc, voff, (16 * s + t) * row_bytes, 0));
+  };
+  auto compute = [&](const f32x4 (&bb)[4], int s) {
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      a[mt] = *reinterpret_cast<const f32x4*>(e_lds + ((mt * S16 + s) * 64 + lane) * 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bb[t][j], acc[mt][j], 0, 0, 0);
+      }
+    }
+  };
+  load_b(b0, 0);
+  int s = 0;
+  for (; s + 2 < S16; s += 2) {  // steady state: both register sets are always reloaded
+    load_b(b1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the MFMAs it overlaps with
+    compute(b0, s);
+    load_b(b0, s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(b1, s + 1);
+  }
+  {  // peeled tail: one or two super-steps left, no further prefetch
+    const bool two = (s + 2 == S16);
+    if (two) load_b(b1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(b0, s);
+    __builtin_amdgcn_sched_barrier(0);
+    if (two) compute(b1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: lane holds rows 4g+reg of each row tile, pixels p0..p0+3 (column tiles 0..3).
+  // Rows >= Q fall outside out_rsrc's range and are dropped by the hardware.
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, voff,
+                                             (q0 + mt * 16 + r) * row_bytes, 0);
+    }
+  }
+}
+
+}  // namespace wm2f
+
+using namespace wm2f;
+
+extern "C" int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out, int B, int Q, int C, int HW,
+                                    int dtype, void* stream) {
+  const char* who = "wm2f_mask_einsum_fwd";
+  WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
+  WM2F_REQUIRE(emb && pix && out, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && Q > 0 && C > 0 && HW > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(C % 16 == 0, "%s: C=%d must be a multiple of 16", who, C);
+  WM2F_REQUIRE(HW % 4 == 0, "%s: HW=%d must be a multiple of 4", who, HW);
+  WM2F_REQUIRE((int64_t)C * HW * 4 < (1ll << 31) && (int64_t)(Q + 16) * HW * 4 < (1ll << 31),
+               "%s: one image's pix / out slab must stay below 2 GiB (32-bit buffer offsets)", who);
+  // row tiles per pass: as many as fit 160 KiB of LDS, at most 7 (accumulator registers)
+  int mt_cap = (160 * 1024) / (16 * C * 4);
+  if (mt_cap > 7) mt_cap = 7;
+  WM2F_REQUIRE(mt_cap >= 1, "%s: C=%d too large for the LDS-resident emb tile", who, C);
+  const int q_chunks = ceil_div(Q, 16 * mt_cap);
+  const int MT = ceil_div(ceil_div(Q, q_chunks), 16);
+  const int n_strips = ceil_div(HW, kStripPix);
+  dim3 grid(ceil_div(n_strips, kEinsumWaves), B * q_chunks);
+  const size_t lds = (size_t)MT * 16 * C * 4;
+  hipStream_t st = (hipStream_t)stream;
+#define WM2F_LAUNCH(MTv)                                                                                     \
+  case MTv: {                                                                                                \
+    auto kfn = mask_einsum_fwd_kernel<MTv>;                                                                  \
+    if (lds > 64 * 1024) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) {                                                                                 \
+        set_error("%s: cannot raise dynamic LDS to %zu: %s", who, lds, hipGetErrorString(e));               \
+        return WM2F_ELAUNCH;                                                                                 \
+      }                                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kfn, grid, dim3(kEinsumWaves* kWave), lds, st, (const float*)emb, (const float*)pix,  \
+                       (float*)out, Q, C, HW, q_chunks);                                                     \
+  } break;
+  switch (MT) {
+    WM2F_LAUNCH(1) WM2F_LAUNCH(2) WM2F_LAUNCH(3) WM2F_LAUNCH(4) WM2F_LAUNCH(5) WM2F_LAUNCH(6) WM2F_LAUNCH(7)
+    default:
+      set_error("%s: internal: MT=%d", who, MT);
+      return WM2F_EINVAL;
+  }
+#undef WM2F_LAUNCH
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

@@ -1,0 +1,320 @@
+// K2: masked cross-attention of the transformer decoder (queries x feature-map keys).
+// Replaces the attention arithmetic of nn.MultiheadAttention as called at transformers
+// modeling_mask2former.py:1644-1650 (torch/nn/functional.py:6578-6600):
+//     softmax(bias + (q / sqrt(D)) k^T) v,   bias = -inf where the predicted mask blocks a key,
+// with the rule of :1912-1914 (a query whose row is fully blocked attends everywhere) applied
+// through row_open.  The x num_heads replicated bool mask (:2052) is never materialised: every
+// head reads the same (B, Q, N) byte mask.
+//
+//   q (B, Q, heads*D) pre-scaled;  k, v (B, N, heads*D);  mask (B, Q, N) u8;  row_open (B, Q) i32
+//   out (B, Q, heads*D);  lse (B, heads, Q)
+//
+// Structure: flash-style, split over keys.  grid = (n_splits * q_chunks, heads, B); each of the 4
+// waves of a workgroup walks 16-key tiles of its split with an online softmax, all in fp32 on
+// v_mfma_f32_16x16x4_f32:
+//   S^T = K Q^T   (A = K tile [key][d], B = Q^T [d][query])  -> C layout: column = query (lane&15),
+//                  rows = keys 4g+r.  Computing S TRANSPOSED makes the softmax output directly the
+//                  B operand of the next product, no lane movement:
+//   O^T += V^T P^T (A = V^T [d][key], B = P^T [key][query]).
+// Partial (m, l, O) of the 4 waves are merged through LDS, one partial per (split) goes to the
+// workspace, and a second kernel merges the splits and writes out / lse.
+//
+// Roofline: at fp32 the op is MFMA-bound, not HBM-bound: 4*B*heads*Q*N*D flop
+// (13.4 GFLOP at N = 16384, config 2) vs 2*B*N*heads*D*4 B of K/V (268 MB).
+#include "common.h"
+
+namespace wm2f {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kXWaves = 4;
+
+static inline int xattn_splits(int B, int heads, int N) {
+  const int n_tiles = ceil_div(N, 16);
+  int s = ceil_div(1024, B * heads);  // aim at >= 4 workgroups per CU-quarter of the chip
+  const int max_s = ceil_div(n_tiles, kXWaves);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+
+template <int NQT, int D>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, float* __restrict__ ws, int Q, int N,
+    int heads, int n_splits, int tiles_per_split) {
+  constexpr int DK = D / 4;   // k-steps of S^T: lane group g owns d = DK*g .. DK*g+DK-1
+  constexpr int DT = D / 16;  // 16-row tiles of O^T
+  constexpr int QL = NQT * 16;
+  constexpr int RS = D + 4;  // LDS / workspace row: O[D], m, l, pad, pad (keeps float4 alignment)
+  __shared__ __attribute__((aligned(16))) float part[kXWaves][QL][RS];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x % n_splits, qc = blockIdx.x / n_splits;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qc * QL;
+  const int E = heads * D;
+  const float NEG_INF = -INFINITY;
+
+  // ---- Q^T fragments (B operand), kept for the whole kernel
+  float qf[NQT][DK];
+  int qrow[NQT];
+  bool use_mask[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    int qi = q0 + 16 * j + n;
+    if (qi > Q - 1) qi = Q - 1;  // padding rows replay the last query; never stored
+    qrow[j] = qi;
+    const float* qp = q + ((int64_t)b * Q + qi) * E + h * D + DK * g;
+#pragma unroll
+    for (int t = 0; t < DK; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(qp + t);
+      qf[j][t] = x.x; qf[j][t + 1] = x.y; qf[j][t + 2] = x.z; qf[j][t + 3] = x.w;
+    }
+    use_mask[j] = mask != nullptr && (row_open == nullptr || row_open[(int64_t)b * Q + qi] != 0);
+  }
+
+  f32x4 o[DT][NQT];
+  float m[NQT], l[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    m[j] = NEG_INF;
+    l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int n_tiles = ceil_div(N, 16);
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+  const bool n_al4 = (N & 3) == 0;
+
+  for (int tile = split * tiles_per_split + wave; tile < t_end; tile += kXWaves) {
+    const int key0 = tile * 16;
+    // K fragment (A operand of S^T): lane (key = key0+n, d = DK*g + t)
+    float kf[DK];
+    {
+      int kk = key0 + n;
+      if (kk > N - 1) kk = N - 1;
+      const float* kp = k + ((int64_t)b * N + kk) * E + h * D + DK * g;
+#pragma unroll
+      for (int t = 0; t < DK; t += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(kp + t);
+        kf[t] = x.x; kf[t + 1] = x.y; kf[t + 2] = x.z; kf[t + 3] = x.w;
+      }
+    }
+    // V^T fragments (A operand of O^T): lane (d = 16i+n, key = key0+4g+t)
+    float vf[DT][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int vk = key0 + 4 * g + t;
+      if (vk > N - 1) vk = N - 1;
+      const float* vp = v + ((int64_t)b * N + vk) * E + h * D + n;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) vf[i][t] = vp[16 * i];
+    }
+
+    // ---- S^T = K Q^T
+    f32x4 s[NQT];
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < DK; ++t) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[j][t], s[j], 0, 0, 0);
+    }
+
+    // ---- mask, online softmax (per query = per C column), rescale O
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      uint32_t mb = 0;
+      if (use_mask[j]) {
+        const uint8_t* mp = mask + ((int64_t)b * Q + qrow[j]) * N + key0 + 4 * g;
+        if (n_al4 && key0 + 4 * g + 3 < N) {
+          mb = *reinterpret_cast<const uint32_t*>(mp);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + 4 * g + r < N) mb |= (uint32_t)(mp[r] != 0) << (8 * r);
+        }
+      }
+      float tmax = NEG_INF;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dead = ((mb >> (8 * r)) & 0xffu) != 0 || (key0 + 4 * g + r >= N);
+        s[j][r] = dead ? NEG_INF : s[j][r];
+        tmax = fmaxf(tmax, s[j][r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, kWave));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, kWave));
+      const float m_new = fmaxf(m[j], tmax);
+      const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __expf(m[j] - m_safe);
+      m[j] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[j][r] - m_safe);
+        s[j][r] = p;
+        psum += p;
+      }
+      l[j] = l[j] * alpha + psum;  // lane-local partial sum; lane groups are merged at the end
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i][j] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i][t], s[j][t], o[i][j], 0, 0, 0);
+  }
+
+  // ---- merge the 4 waves through LDS
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    float lt = l[j];
+    lt += __shfl_xor(lt, 16, kWave);
+    lt += __shfl_xor(lt, 32, kWave);
+    float* row = &part[wave][16 * j + n][0];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(row + 16 * i + 4 * g) = o[i][j];
+    if (g == 0) {
+      row[D] = m[j];
+      row[D + 1] = lt;
+    }
+  }
+  __syncthreads();
+  // thread -> (query row, float4 chunk of the RS-wide row); chunk D/4 carries (m, l)
+  constexpr int CH = D / 4 + 1;
+  for (int idx = threadIdx.x; idx < QL * CH; idx += kXWaves * kWave) {
+    const int ql = idx / CH, c = idx - ql * CH;
+    const int qi = q0 + ql;
+    if (qi >= Q) continue;
+    float mw[kXWaves], M = NEG_INF;
+#pragma unroll
+    for (int w = 0; w < kXWaves; ++w) {
+      mw[w] = part[w][ql][D];
+      M = fmaxf(M, mw[w]);
+    }
+    const float Ms = (M == NEG_INF) ? 0.f : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < kXWaves; ++w) {
+      const float sc = __expf(mw[w] - Ms);
+      if (c < D / 4) {
+        const float4 x = *reinterpret_cast<const float4*>(&part[w][ql][4 * c]);
+        acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w;
+      } else {
+        L += sc * part[w][ql][D + 1];
+      }
+    }
+    float* wrow = ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * RS;
+    if (c < D / 4)
+      *reinterpret_cast<float4*>(wrow + 4 * c) = acc;
+    else
+      *reinterpret_cast<float4*>(wrow + D) = make_float4(M, L, 0.f, 0.f);
+  }
+}
+
+// Merge the per-split partials: one thread per (b, h, q, float4 chunk of D).
+template <int D>
+__global__ __launch_bounds__(256) void masked_xattn_merge_kernel(const float* __restrict__ ws,
+                                                                 float* __restrict__ out, float* __restrict__ lse,
+                                                                 int B, int heads, int Q, int n_splits) {
+  constexpr int RS = D + 4, CH = D / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * heads * Q * CH;
+  if (idx >= total) return;
+  const int c = (int)(idx % CH);
+  const int64_t row = idx / CH;  // (b*heads + h)*Q + q
+  const int qi = (int)(row % Q);
+  const int64_t bh = row / Q;
+  const int h = (int)(bh % heads), b = (int)(bh / heads);
+  const float* base = ws + row * n_splits * RS;
+  float M = -INFINITY;
+  for (int s = 0; s < n_splits; ++s) M = fmaxf(M, base[s * RS + D]);
+  const float Ms = (M == -INFINITY) ? 0.f : M;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float L = 0.f;
+  for (int s = 0; s < n_splits; ++s) {
+    const float sc = __expf(base[s * RS + D] - Ms);
+    const float4 x = *reinterpret_cast<const float4*>(base + s * RS + 4 * c);
+    acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w;
+    L += sc * base[s * RS + D + 1];
+  }
+  const float inv = 1.f / L;
+  *reinterpret_cast<float4*>(out + ((int64_t)b * Q + qi) * heads * D + h * D + 4 * c) =
+      make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (lse != nullptr && c == 0) lse[row] = M + logf(L);
+}
+
+}  // namespace wm2f
+
+using namespace wm2f;
+
+extern "C" int64_t wm2f_masked_xattn_workspace(int B, int heads, int Q, int N, int D) {
+  if (B <= 0 || heads <= 0 || Q <= 0 || N <= 0 || D <= 0) return 0;
+  return (int64_t)B * heads * Q * xattn_splits(B, heads, N) * (D + 4) * 4;
+}
+
+extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v, const void* mask,
+                                     const void* row_open, void* out, void* lse, void* workspace, int B, int heads,
+                                     int Q, int N, int D, int dtype, void* stream) {
+  const char* who = "wm2f_masked_xattn_fwd";
+  WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
+  WM2F_REQUIRE(q && k && v && out && workspace, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && heads > 0 && Q > 0 && N > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {16,32,64}", who, D);
+  WM2F_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads / B exceed the grid limits", who);
+  const int n_splits = xattn_splits(B, heads, N);
+  const int n_tiles = ceil_div(N, 16);
+  const int tps = ceil_div(n_tiles, n_splits);
+  // query row tiles per pass: 7 (D <= 32) or 3 (D = 64, register budget)
+  const int cap = (D == 64) ? 3 : 7;
+  const int q_tiles = ceil_div(Q, 16);
+  const int q_chunks = ceil_div(q_tiles, cap);
+  int nqt = ceil_div(q_tiles, q_chunks);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(kXWaves * kWave);
+#define WM2F_XL(NQTv, Dv)                                                                                      \
+  {                                                                                                            \
+    dim3 grid(n_splits* ceil_div(Q, NQTv * 16), heads, B);                                                     \
+    hipLaunchKernelGGL((masked_xattn_fwd_kernel<NQTv, Dv>), grid, block, 0, st, (const float*)q,               \
+                       (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,           \
+                       (float*)workspace, Q, N, heads, n_splits, tps);                                         \
+  }
+#define WM2F_XD(Dv)                                  \
+  if (nqt <= 1) WM2F_XL(1, Dv)                       \
+  else if (nqt <= 2) WM2F_XL(2, Dv)                  \
+  else if (nqt <= 4) WM2F_XL(4, Dv)                  \
+  else WM2F_XL(7, Dv)
+  if (D == 16) {
+    WM2F_XD(16)
+  } else if (D == 32) {
+    WM2F_XD(32)
+  } else {
+    if (nqt <= 1) WM2F_XL(1, 64)
+    else if (nqt <= 2) WM2F_XL(2, 64)
+    else WM2F_XL(3, 64)
+  }
+#undef WM2F_XD
+#undef WM2F_XL
+  WM2F_CHECK_LAUNCH(who);
+  const int64_t total = (int64_t)B * heads * Q * (D / 4);
+  dim3 mgrid((unsigned)ceil_div64(total, 256));
+  if (D == 16)
+    hipLaunchKernelGGL((masked_xattn_merge_kernel<16>), mgrid, dim3(256), 0, st, (const float*)workspace,
+                       (float*)out, (float*)lse, B, heads, Q, n_splits);
+  else if (D == 32)
+    hipLaunchKernelGGL((masked_xattn_merge_kernel<32>), mgrid, dim3(256), 0, st, (const float*)workspace,
+                       (float*)out, (float*)lse, B, heads, Q, n_splits);
+  else
+    hipLaunchKernelGGL((masked_xattn_merge_kernel<64>), mgrid, dim3(256), 0, st, (const float*)workspace,
+                       (float*)out, (float*)lse, B, heads, Q, n_splits);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

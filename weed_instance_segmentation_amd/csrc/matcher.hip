@@ -1,0 +1,284 @@
+// K4: Hungarian-matcher cost matrices, and the point sampler shared with the loss.
+// Replaces Mask2FormerHungarianMatcher.forward up to the scipy solver -- transformers
+// modeling_mask2former.py:444-472 -- with sample_point (:245-274), the pair-wise sigmoid CE
+// (:350-374) and the pair-wise dice (:328-347).
+//
+// The reference loops over images and prediction levels, launching ~10 small ops and forcing one
+// device->host copy per (image, level): B x 10 syncs per step.  Here every level of one image is
+// covered by two launches (target sampling, cost), nothing syncs, and the caller copies ALL cost
+// matrices to the host once.
+//
+// Numerics: the sampled values are fp32 with grid_sample's arithmetic; the softplus / sigmoid
+// terms and every sum over the P points are carried in fp64, so the cost is within fp32 round-off
+// of the exact value -- assignments are stable under that.
+#include "common.h"
+
+namespace wm2f {
+
+// grid_sample(bilinear, zeros, align_corners=False) of one (H, W) map at normalised (x, y).
+template <typename T>
+__device__ __forceinline__ float bilinear_zeros(const T* __restrict__ img, int H, int W, float lx, float ly) {
+  const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+  const float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+  const float y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  if (!(x > -1.f && x < (float)W && y > -1.f && y < (float)H)) return 0.f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+  const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
+  const T* p = img + (int64_t)y0 * W + x0;
+  float r = 0.f;
+  if (yt && xl) r += (float)p[0] * (fx0 * fy0);
+  if (yt && xr) r += (float)p[1] * (fx1 * fy0);
+  if (yb && xl) r += (float)p[W] * (fx0 * fy1);
+  if (yb && xr) r += (float)p[W + 1] * (fx1 * fy1);
+  return r;
+}
+
+// out[n][p] = bilinear(feat[n], pts[n][p])          grid (ceil(P/256), N)
+template <typename T>
+__global__ __launch_bounds__(256) void point_sample_fwd_kernel(const T* __restrict__ feat,
+                                                               const float* __restrict__ pts,
+                                                               float* __restrict__ out, int H, int W, int P,
+                                                               int64_t pts_stride_n) {
+  const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (p >= P) return;
+  const float* pp = pts + n * pts_stride_n + (int64_t)p * 2;
+  out[(int64_t)n * P + p] = bilinear_zeros(feat + (int64_t)n * H * W, H, W, pp[0], pp[1]);
+}
+
+__global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __restrict__ grad_out,
+                                                               const float* __restrict__ pts,
+                                                               float* __restrict__ grad_feat, int H, int W, int P) {
+  const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (p >= P) return;
+  const float* pp = pts + ((int64_t)n * P + p) * 2;
+  const float go = grad_out[(int64_t)n * P + p];
+  const float gx = 2.f * pp[0] - 1.f, gy = 2.f * pp[1] - 1.f;
+  const float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+  const float y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  if (!(x > -1.f && x < (float)W && y > -1.f && y < (float)H)) return;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+  const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
+  float* g = grad_feat + (int64_t)n * H * W + (int64_t)y0 * W + x0;
+  if (yt && xl) atomicAdd(g, go * fx0 * fy0);
+  if (yt && xr) atomicAdd(g + 1, go * fx1 * fy0);
+  if (yb && xl) atomicAdd(g + W, go * fx0 * fy1);
+  if (yb && xr) atomicAdd(g + W + 1, go * fx1 * fy1);
+}
+
+// Targets of ONE image, all levels: tm[lvl][t][p].          grid (ceil(P/256), T_b, NL)
+template <typename T>
+__global__ __launch_bounds__(256) void matcher_sample_targets_kernel(const T* __restrict__ tgt /* (T_b,Ht,Wt) */,
+                                                                     const float* __restrict__ points /* +b */,
+                                                                     float* __restrict__ tm /* + tgt_offset*P */,
+                                                                     int Ht, int Wt, int P, int64_t pts_stride_lvl,
+                                                                     int64_t tm_stride_lvl) {
+  const int p = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y, lvl = blockIdx.z;
+  if (p >= P) return;
+  const float* pp = points + lvl * pts_stride_lvl + (int64_t)p * 2;
+  tm[lvl * tm_stride_lvl + (int64_t)t * P + p] = bilinear_zeros(tgt + (int64_t)t * Ht * Wt, Ht, Wt, pp[0], pp[1]);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+// Cost rows of ONE image: block = (group of QG queries, level); loops over target chunks of TC.
+constexpr int kQG = 2, kTC = 8;
+
+__global__ __launch_bounds__(256) void matcher_cost_kernel(
+    const float* __restrict__ mask_logits /* + b*Q*h*w */, const float* __restrict__ class_logits /* + b*Q*C1 */,
+    const float* __restrict__ tm /* + tgt_offset*P */, const int64_t* __restrict__ tgt_classes /* + tgt_offset */,
+    const float* __restrict__ points /* + b*P*2 */, float* __restrict__ cost /* + b*Q*Tmax */, int Q, int C1, int h,
+    int w, int P, int T, int Tmax, int64_t ml_stride_lvl, int64_t cl_stride_lvl, int64_t pts_stride_lvl,
+    int64_t tm_stride_lvl, int64_t cost_stride_lvl, float w_class, float w_mask, float w_dice) {
+  constexpr int NV = kQG * kTC * 3 + kTC + kQG * 2;  // values reduced per chunk
+  __shared__ double red[4][NV];
+  const int lvl = blockIdx.y, q0 = blockIdx.x * kQG;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* ml = mask_logits + lvl * ml_stride_lvl;
+  const float* pts = points + lvl * pts_stride_lvl;
+  const float* tml = tm + lvl * tm_stride_lvl;
+
+  for (int t0 = 0; t0 < T; t0 += kTC) {
+    double a_pos[kQG][kTC], a_neg[kQG][kTC], a_sig[kQG][kTC], s_t[kTC], s_neg[kQG], s_sig[kQG];
+#pragma unroll
+    for (int c = 0; c < kTC; ++c) {
+      s_t[c] = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < kQG; ++qq) a_pos[qq][c] = a_neg[qq][c] = a_sig[qq][c] = 0.0;
+    }
+#pragma unroll
+    for (int qq = 0; qq < kQG; ++qq) s_neg[qq] = s_sig[qq] = 0.0;
+
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const float px = pts[2 * p], py = pts[2 * p + 1];
+      double tv[kTC];
+#pragma unroll
+      for (int c = 0; c < kTC; ++c) {
+        tv[c] = (t0 + c < T) ? (double)tml[(int64_t)(t0 + c) * P + p] : 0.0;
+        s_t[c] += tv[c];
+      }
+#pragma unroll
+      for (int qq = 0; qq < kQG; ++qq) {
+        int qi = q0 + qq;
+        if (qi > Q - 1) qi = Q - 1;
+        const double x = (double)bilinear_zeros(ml + (int64_t)qi * h * w, h, w, px, py);
+        const double e = exp(-fabs(x));
+        const double lg = log1p(e);
+        const double pos = fmax(-x, 0.0) + lg;  // BCEWithLogits(x, 1)
+        const double neg = fmax(x, 0.0) + lg;   // BCEWithLogits(x, 0)
+        const double sig = x >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+        s_neg[qq] += neg;
+        s_sig[qq] += sig;
+#pragma unroll
+        for (int c = 0; c < kTC; ++c) {
+          a_pos[qq][c] += pos * tv[c];
+          a_neg[qq][c] += neg * tv[c];
+          a_sig[qq][c] += sig * tv[c];
+        }
+      }
+    }
+    // ---- block reduction: wave shuffles, then 4 partials through LDS
+    int vi = 0;
+    auto put = [&](double v) {
+      v = wave_sum(v);
+      if (lane == 0) red[wave][vi] = v;
+      ++vi;
+    };
+#pragma unroll
+    for (int qq = 0; qq < kQG; ++qq)
+#pragma unroll
+      for (int c = 0; c < kTC; ++c) {
+        put(a_pos[qq][c]);
+        put(a_neg[qq][c]);
+        put(a_sig[qq][c]);
+      }
+#pragma unroll
+    for (int c = 0; c < kTC; ++c) put(s_t[c]);
+#pragma unroll
+    for (int qq = 0; qq < kQG; ++qq) {
+      put(s_neg[qq]);
+      put(s_sig[qq]);
+    }
+    __syncthreads();
+    if (threadIdx.x < kQG * kTC) {
+      const int qq = threadIdx.x / kTC, c = threadIdx.x % kTC;
+      const int qi = q0 + qq, t = t0 + c;
+      if (qi < Q && t < T) {
+        auto R = [&](int i) { return red[0][i] + red[1][i] + red[2][i] + red[3][i]; };
+        const double apos = R((qq * kTC + c) * 3 + 0), aneg = R((qq * kTC + c) * 3 + 1);
+        const double asig = R((qq * kTC + c) * 3 + 2);
+        const double st = R(kQG * kTC * 3 + c);
+        const double sneg = R(kQG * kTC * 3 + kTC + qq * 2), ssig = R(kQG * kTC * 3 + kTC + qq * 2 + 1);
+        const double cost_mask = (apos + (sneg - aneg)) / (double)P;
+        const double cost_dice = 1.0 - (2.0 * asig + 1.0) / (ssig + st + 1.0);
+        // -softmax(class_logits)[target class], HF:445-449
+        const float* cl = class_logits + lvl * cl_stride_lvl + (int64_t)qi * C1;
+        double mx = -1e300;
+        for (int k2 = 0; k2 < C1; ++k2) mx = fmax(mx, (double)cl[k2]);
+        double den = 0.0;
+        for (int k2 = 0; k2 < C1; ++k2) den += exp((double)cl[k2] - mx);
+        const int64_t tc = tgt_classes[t];
+        const double prob = (tc >= 0 && tc < C1) ? exp((double)cl[tc] - mx) / den : 0.0;
+        double cst = (double)w_mask * cost_mask - (double)w_class * prob + (double)w_dice * cost_dice;
+        float cf = (float)cst;
+        cf = fminf(cf, 1e10f);
+        cf = fmaxf(cf, -1e10f);
+        if (cf != cf) cf = 0.f;
+        cost[lvl * cost_stride_lvl + (int64_t)qi * Tmax + t] = cf;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace wm2f
+
+using namespace wm2f;
+
+extern "C" int64_t wm2f_matcher_workspace(int NL, int B, int Q, int P, int Tsum) {
+  (void)B;
+  (void)Q;
+  if (NL <= 0 || P <= 0 || Tsum <= 0) return 0;
+  return (int64_t)NL * Tsum * P * 4;
+}
+
+extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const void* tgt_masks,
+                                 int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes,
+                                 const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1, int h,
+                                 int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                                 void* stream) {
+  const char* who = "wm2f_matcher_cost";
+  WM2F_REQUIRE(mask_logits && class_logits && tgt_offset && points && cost, "%s: null pointer", who);
+  WM2F_REQUIRE(NL > 0 && B > 0 && Q > 0 && C1 > 0 && h > 0 && w > 0 && Ht > 0 && Wt > 0 && P > 0,
+               "%s: non-positive size", who);
+  WM2F_REQUIRE(tgt_dtype == 0 || tgt_dtype == 1, "%s: tgt_dtype must be 0 (fp32) or 1 (uint8)", who);
+  WM2F_REQUIRE(NL <= 65535, "%s: too many levels", who);
+  const int Tsum = tgt_offset[B];
+  WM2F_REQUIRE(tgt_offset[0] == 0 && Tsum >= 0, "%s: bad tgt_offset", who);
+  if (Tsum == 0) return WM2F_OK;
+  WM2F_REQUIRE(tgt_masks && tgt_classes && workspace, "%s: null pointer", who);
+  hipStream_t st = (hipStream_t)stream;
+  float* tm = (float*)workspace;
+  const int64_t tm_stride_lvl = (int64_t)Tsum * P;
+  const int64_t pts_stride_lvl = (int64_t)B * P * 2;
+  for (int b = 0; b < B; ++b) {
+    const int T = tgt_offset[b + 1] - tgt_offset[b];
+    WM2F_REQUIRE(T >= 0 && T <= Tmax && T <= 65535, "%s: image %d has %d targets (Tmax=%d)", who, b, T, Tmax);
+    if (T == 0) continue;
+    const float* pts_b = (const float*)points + (int64_t)b * P * 2;
+    float* tm_b = tm + (int64_t)tgt_offset[b] * P;
+    dim3 ga(ceil_div(P, 256), T, NL);
+    if (tgt_dtype == 0)
+      hipLaunchKernelGGL(matcher_sample_targets_kernel<float>, ga, dim3(256), 0, st,
+                         (const float*)tgt_masks + (int64_t)tgt_offset[b] * Ht * Wt, pts_b, tm_b, Ht, Wt, P,
+                         pts_stride_lvl, tm_stride_lvl);
+    else
+      hipLaunchKernelGGL(matcher_sample_targets_kernel<uint8_t>, ga, dim3(256), 0, st,
+                         (const uint8_t*)tgt_masks + (int64_t)tgt_offset[b] * Ht * Wt, pts_b, tm_b, Ht, Wt, P,
+                         pts_stride_lvl, tm_stride_lvl);
+    dim3 gb(ceil_div(Q, kQG), NL);
+    hipLaunchKernelGGL(matcher_cost_kernel, gb, dim3(256), 0, st,
+                       (const float*)mask_logits + (int64_t)b * Q * h * w,
+                       (const float*)class_logits + (int64_t)b * Q * C1, tm_b,
+                       (const int64_t*)tgt_classes + tgt_offset[b], pts_b, (float*)cost + (int64_t)b * Q * Tmax, Q, C1,
+                       h, w, P, T, Tmax, (int64_t)B * Q * h * w, (int64_t)B * Q * C1, pts_stride_lvl, tm_stride_lvl,
+                       (int64_t)B * Q * Tmax, w_class, w_mask, w_dice);
+  }
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, void* out, int N, int H,
+                                     int W, int P, void* stream) {
+  const char* who = "wm2f_point_sample_fwd";
+  WM2F_REQUIRE(feat && pts && out, "%s: null pointer", who);
+  WM2F_REQUIRE(N > 0 && H > 0 && W > 0 && P > 0 && N <= 65535, "%s: bad size", who);
+  WM2F_REQUIRE(feat_dtype == 0 || feat_dtype == 1, "%s: feat_dtype must be 0 (fp32) or 1 (uint8)", who);
+  dim3 grid(ceil_div(P, 256), N);
+  if (feat_dtype == 0)
+    hipLaunchKernelGGL(point_sample_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat,
+                       (const float*)pts, (float*)out, H, W, P, (int64_t)P * 2);
+  else
+    hipLaunchKernelGGL(point_sample_fwd_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)feat, (const float*)pts, (float*)out, H, W, P, (int64_t)P * 2);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_point_sample_bwd(const void* grad_out, const void* pts, void* grad_feat, int N, int H, int W,
+                                     int P, void* stream) {
+  const char* who = "wm2f_point_sample_bwd";
+  WM2F_REQUIRE(grad_out && pts && grad_feat, "%s: null pointer", who);
+  WM2F_REQUIRE(N > 0 && H > 0 && W > 0 && P > 0 && N <= 65535, "%s: bad size", who);
+  hipLaunchKernelGGL(point_sample_bwd_kernel, dim3(ceil_div(P, 256), N), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)grad_out, (const float*)pts, (float*)grad_feat, H, W, P);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

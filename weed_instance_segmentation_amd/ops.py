@@ -1,0 +1,249 @@
+"""Python face of the libwm2f kernels: argument checking, pointer plumbing, autograd glue.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only.  Every function here
+launches hand-written HIP through the C ABI (include/wm2f.h) on the caller's current stream and
+RAISES if the tensors are not on a GPU or the library is missing -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence
+
+import torch
+
+from . import _lib
+from ._lib import WM2F_F32, check, host_i32, load
+
+
+def _p(t: torch.Tensor | None):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.Wm2fError(f"{name} is on {t.device}: the wm2f kernels run on a GPU only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------- K1
+class _MSDeformAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, loc, attn_w, level_hw):
+        value, loc, attn_w = _req(value, "value"), _req(loc, "loc"), _req(attn_w, "attn_w")
+        B, S, H, D = value.shape
+        _, Q, _, L, P, _ = loc.shape
+        if loc.shape != (B, Q, H, L, P, 2) or attn_w.shape != (B, Q, H, L, P):
+            raise ValueError(f"msdeform: shapes disagree: value {tuple(value.shape)} loc {tuple(loc.shape)} "
+                             f"attn_w {tuple(attn_w.shape)}")
+        out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
+        lv = host_i32([x for hw in level_hw for x in hw])
+        with torch.cuda.device(value.device):
+            check(load().wm2f_msdeform_fwd(_p(value), _p(loc), _p(attn_w), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32,
+                                           _stream(value)), "wm2f_msdeform_fwd")
+        ctx.save_for_backward(value, loc, attn_w)
+        ctx.level_hw = tuple(tuple(int(x) for x in hw) for hw in level_hw)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, loc, attn_w = ctx.saved_tensors
+        grad_out = _req(grad_out, "grad_out")
+        B, S, H, D = value.shape
+        _, Q, _, L, P, _ = loc.shape
+        g_value = torch.zeros_like(value)
+        g_loc = torch.empty_like(loc)
+        g_w = torch.empty_like(attn_w)
+        lv = host_i32([x for hw in ctx.level_hw for x in hw])
+        with torch.cuda.device(value.device):
+            check(load().wm2f_msdeform_bwd(_p(value), _p(loc), _p(attn_w), _p(grad_out), _p(g_value), _p(g_loc),
+                                           _p(g_w), lv, B, S, Q, H, D, L, P, WM2F_F32, _stream(value)),
+                  "wm2f_msdeform_bwd")
+        return g_value, g_loc, g_w, None
+
+
+def ms_deform_attn(value: torch.Tensor, level_hw: Sequence[Sequence[int]], loc: torch.Tensor,
+                   attn_w: torch.Tensor) -> torch.Tensor:
+    """K1 -- multi_scale_deformable_attention (HF:798-837).
+    value (B,S,heads,D), loc (B,Q,heads,L,P,2), attn_w (B,Q,heads,L,P) -> (B,Q,heads*D)."""
+    return _MSDeformAttn.apply(value, loc, attn_w, level_hw)
+
+
+def ms_deform_attn_fused(value: torch.Tensor, level_hw, offsets: torch.Tensor, logits: torch.Tensor,
+                         ref: torch.Tensor) -> torch.Tensor:
+    """K1 with the softmax / location prologue of HF:983-1002 fused (inference path, no autograd).
+    offsets (B,Q,heads,L,P,2) raw, logits (B,Q,heads,L*P) raw, ref (Q,L,2)."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (value, offsets, logits)):
+        raise RuntimeError("ms_deform_attn_fused has no backward; use ms_deform_attn when training")
+    value, offsets, logits, ref = _req(value, "value"), _req(offsets, "offsets"), _req(logits, "logits"), _req(ref, "ref")
+    B, S, H, D = value.shape
+    _, Q, _, L, P, _ = offsets.shape
+    if logits.shape != (B, Q, H, L * P) or ref.shape != (Q, L, 2):
+        raise ValueError("ms_deform_attn_fused: shapes disagree")
+    out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
+    lv = host_i32([x for hw in level_hw for x in hw])
+    with torch.cuda.device(value.device):
+        check(load().wm2f_msdeform_fused_fwd(_p(value), _p(offsets), _p(logits), _p(ref), _p(out), lv, B, S, Q, H, D, L,
+                                             P, WM2F_F32, _stream(value)), "wm2f_msdeform_fused_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- K3
+class _MaskEinsum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, pix):
+        emb, pix = _req(emb, "emb"), _req(pix, "pix")
+        B, Q, C = emb.shape
+        if pix.dim() != 4 or pix.shape[0] != B or pix.shape[1] != C:
+            raise ValueError(f"mask_einsum: emb {tuple(emb.shape)} vs pix {tuple(pix.shape)}")
+        Hh, Ww = pix.shape[2:]
+        out = torch.empty(B, Q, Hh, Ww, device=emb.device, dtype=emb.dtype)
+        with torch.cuda.device(emb.device):
+            check(load().wm2f_mask_einsum_fwd(_p(emb), _p(pix), _p(out), B, Q, C, Hh * Ww, WM2F_F32, _stream(emb)),
+                  "wm2f_mask_einsum_fwd")
+        ctx.save_for_backward(emb, pix)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        # Two plain batched GEMMs (library GEMM: rocBLAS / hipBLASLt through torch.bmm).
+        emb, pix = ctx.saved_tensors
+        B, Q, C = emb.shape
+        go = grad_out.reshape(B, Q, -1)
+        g_emb = torch.bmm(go, pix.reshape(B, C, -1).transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        g_pix = torch.bmm(emb.transpose(1, 2), go).view_as(pix) if ctx.needs_input_grad[1] else None
+        return g_emb, g_pix
+
+
+def mask_einsum(emb: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
+    """K3 -- einsum('bqc,bchw->bqhw') (HF:2046) on the fp32 matrix cores."""
+    return _MaskEinsum.apply(emb, pix)
+
+
+def attn_mask_build(logits: torch.Tensor, size: Sequence[int]):
+    """HF:2048-2054 + HF:1912-1914: (mask (B,Q,Hn*Wn) uint8 1=blocked, row_open (B,Q) int32).  No grad."""
+    logits = _req(logits.detach(), "logits")
+    B, Q, H, W = logits.shape
+    Hn, Wn = int(size[0]), int(size[1])
+    mask = torch.empty(B, Q, Hn * Wn, device=logits.device, dtype=torch.uint8)
+    row_open = torch.empty(B, Q, device=logits.device, dtype=torch.int32)
+    with torch.cuda.device(logits.device):
+        check(load().wm2f_attn_mask_build(_p(logits), _p(mask), _p(row_open), B, Q, H, W, Hn, Wn, _stream(logits)),
+              "wm2f_attn_mask_build")
+    return mask, row_open
+
+
+# ----------------------------------------------------------------------------------------- K2
+class _MaskedXAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, row_open, heads):
+        q, k, v = _req(q, "q"), _req(k, "k"), _req(v, "v")
+        B, Q, E = q.shape
+        N = k.shape[1]
+        D = E // heads
+        if k.shape != (B, N, E) or v.shape != (B, N, E) or D * heads != E:
+            raise ValueError(f"masked_xattn: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} heads {heads}")
+        if mask is not None:
+            mask = _req(mask, "mask", torch.uint8)
+            if mask.shape != (B, Q, N):
+                raise ValueError(f"masked_xattn: mask {tuple(mask.shape)} != {(B, Q, N)}")
+        if row_open is not None:
+            row_open = _req(row_open, "row_open", torch.int32)
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, Q, device=q.device, dtype=torch.float32)
+        lib = load()
+        ws = torch.empty(int(lib.wm2f_masked_xattn_workspace(B, heads, Q, N, D)), device=q.device, dtype=torch.uint8)
+        with torch.cuda.device(q.device):
+            check(lib.wm2f_masked_xattn_fwd(_p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(ws), B,
+                                            heads, Q, N, D, WM2F_F32, _stream(q)), "wm2f_masked_xattn_fwd")
+        ctx.save_for_backward(q, k, v, mask, row_open, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError("masked_xattn backward (wm2f_masked_xattn_bwd) is not built yet")
+
+
+def masked_xattn(q, k, v, mask, row_open, heads: int) -> torch.Tensor:
+    """K2 -- softmax(bias + q k^T) v with the shared byte mask (HF:1644-1650, TORCHF:6578-6600).
+    q (B,Q,E) pre-scaled by 1/sqrt(D); k, v (B,N,E); mask (B,Q,N) uint8 or None; row_open (B,Q) int32 or None."""
+    return _MaskedXAttn.apply(q, k, v, mask, row_open, heads)
+
+
+# ----------------------------------------------------------------------------------------- K4
+def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, points, w_class, w_mask, w_dice):
+    """K4 -- all cost matrices of a step in one go (HF:444-472), no sync.
+
+    mask_logits (NL,B,Q,h,w); class_logits (NL,B,Q,C1); tgt_masks (sum T, Ht, Wt) fp32 or uint8;
+    tgt_counts: python list of T_i; tgt_classes (sum T,) int64; points (NL,B,P,2).
+    Returns cost (NL,B,Q,Tmax) fp32 on the device; columns >= T_i are zero."""
+    mask_logits, class_logits, points = _req(mask_logits, "mask_logits"), _req(class_logits, "class_logits"), _req(points, "points")
+    NL, B, Q, h, w = mask_logits.shape
+    C1 = class_logits.shape[-1]
+    P = points.shape[2]
+    if tgt_masks.dtype == torch.bool:
+        tgt_masks = tgt_masks.view(torch.uint8)
+    tdt = 1 if tgt_masks.dtype == torch.uint8 else 0
+    tgt_masks = _req(tgt_masks, "tgt_masks", torch.uint8 if tdt else torch.float32)
+    tgt_classes = _req(tgt_classes, "tgt_classes", torch.int64)
+    offs = [0]
+    for t in tgt_counts:
+        offs.append(offs[-1] + int(t))
+    Tsum, Tmax = offs[-1], max([int(t) for t in tgt_counts] + [1])
+    if tgt_masks.shape[0] != Tsum or tgt_classes.shape[0] != Tsum or len(tgt_counts) != B:
+        raise ValueError("matcher_cost: target counts disagree with the target tensors")
+    Ht, Wt = tgt_masks.shape[-2:]
+    cost = torch.zeros(NL, B, Q, Tmax, device=mask_logits.device, dtype=torch.float32)
+    lib = load()
+    ws = torch.empty(max(int(lib.wm2f_matcher_workspace(NL, B, Q, P, Tsum)), 4), device=mask_logits.device, dtype=torch.uint8)
+    with torch.cuda.device(mask_logits.device):
+        check(lib.wm2f_matcher_cost(_p(mask_logits), _p(class_logits), _p(tgt_masks), tdt, host_i32(offs), _p(tgt_classes),
+                                    _p(points), _p(cost), _p(ws), NL, B, Q, C1, h, w, Ht, Wt, P, Tmax, float(w_class),
+                                    float(w_mask), float(w_dice), _stream(mask_logits)), "wm2f_matcher_cost")
+    return cost
+
+
+# ----------------------------------------------------------------------------------------- point sampling
+class _PointSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, pts):
+        tdt = 1 if feat.dtype in (torch.uint8, torch.bool) else 0
+        if feat.dtype == torch.bool:
+            feat = feat.view(torch.uint8)
+        feat = _req(feat, "feat", torch.uint8 if tdt else torch.float32)
+        pts = _req(pts, "pts")
+        N, H, W = feat.shape
+        P = pts.shape[1]
+        if pts.shape != (N, P, 2):
+            raise ValueError(f"point_sample: feat {tuple(feat.shape)} pts {tuple(pts.shape)}")
+        out = torch.empty(N, P, device=feat.device, dtype=torch.float32)
+        with torch.cuda.device(feat.device):
+            check(load().wm2f_point_sample_fwd(_p(feat), tdt, _p(pts), _p(out), N, H, W, P, _stream(feat)),
+                  "wm2f_point_sample_fwd")
+        ctx.save_for_backward(pts)
+        ctx.shape = (N, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (pts,) = ctx.saved_tensors
+        N, H, W = ctx.shape
+        grad_out = _req(grad_out, "grad_out")
+        g = torch.zeros(N, H, W, device=pts.device, dtype=torch.float32)
+        with torch.cuda.device(pts.device):
+            check(load().wm2f_point_sample_bwd(_p(grad_out), _p(pts), _p(g), N, H, W, pts.shape[1], _stream(pts)),
+                  "wm2f_point_sample_bwd")
+        return g, None
+
+
+def point_sample(feat: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
+    """sample_point (HF:245-274) for single-channel maps: feat (N,H,W), pts (N,P,2) in [0,1] (x,y) -> (N,P)."""
+    return _PointSample.apply(feat, pts)
