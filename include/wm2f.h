@@ -126,12 +126,14 @@ int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const v
                       float w_dice, void* stream);
 
 /* ---- point sampling (shared by the loss, HF:245-274) ----------------------------------------
- *   feat (N, H, W) fp32 or uint8 (feat_dtype 0 / 1); pts (N, P, 2); out (N, P) fp32.
- * Backward (fp32 feat only): grad_feat (N,H,W) must be zeroed by the caller. */
-int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, void* out, int N, int H,
-                          int W, int P, void* stream);
-int wm2f_point_sample_bwd(const void* grad_out, const void* pts, void* grad_feat, int N, int H, int W,
-                          int P, void* stream);
+ *   feat (N, H, W) fp32 or uint8 (feat_dtype 0 / 1); pts (M, P, 2); out (M, P) fp32.
+ *   map_index: int32 [M] -- row m samples feat[map_index[m]] (matched prediction / target maps are
+ *   sampled in place instead of being gathered into a copy); NULL means M == N, identity.
+ * Backward (fp32 feat only): grad_feat (N,H,W) must be zeroed by the caller (float atomics). */
+int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, const void* map_index,
+                          void* out, int M, int H, int W, int P, void* stream);
+int wm2f_point_sample_bwd(const void* grad_out, const void* pts, const void* map_index, void* grad_feat,
+                          int M, int H, int W, int P, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,98 @@
+"""Whole-module parity on the GPU: the drop-in module (HIP kernels) vs the golden fixture produced by
+transformers 5.15.0 and vs the CPU oracle on the same weights.  Needs an MI355X (-m gpu)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import m2f_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    g = load_golden("full_tiny.npz")
+    cfg = Mask2FormerConfig.from_dict(json.loads(str(g["config_json"])))
+    model = Mask2FormerForUniversalSegmentation(cfg)
+    sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    return g, cfg, model.cuda().eval(), sd
+
+
+def _labels(g, B, dev="cuda", dtype=torch.float32):
+    ml = [T(g[f"mask_labels_{i}"]).to(dtype).to(dev) for i in range(B)]
+    cl = [T(g[f"class_labels_{i}"]).to(dev) for i in range(B)]
+    return ml, cl
+
+
+def test_forward_matches_golden(tiny):
+    g, cfg, model, _ = tiny
+    with torch.no_grad():
+        out = model(pixel_values=T(g["pixel_values"]).cuda(), output_hidden_states=True, output_auxiliary_logits=True)
+    for i, f in enumerate(out.encoder_hidden_states):
+        torch.testing.assert_close(f.cpu(), T(g[f"backbone_{i}"]), rtol=1e-4, atol=1e-4)
+    for i, f in enumerate(out.pixel_decoder_hidden_states):
+        torch.testing.assert_close(f.cpu(), T(g[f"multi_scale_{i}"]), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(out.pixel_decoder_last_hidden_state.cpu(), T(g["mask_features"]), rtol=1e-3, atol=2e-4)
+    # headline bar: mask logits within 1e-3 relative (fp32)
+    ref = T(g["masks_queries_logits"])
+    err = (out.masks_queries_logits.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-3, err
+    torch.testing.assert_close(out.class_queries_logits.cpu(), T(g["class_queries_logits"]), rtol=1e-3, atol=1e-3)
+    for i, aux in enumerate(out.auxiliary_logits):
+        r = T(g[f"aux_masks_{i}"])
+        assert (aux["masks_queries_logits"].cpu() - r).abs().max().item() / r.abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("label_dtype", [torch.float32, torch.uint8])
+def test_loss_and_indices_match_golden(tiny, label_dtype):
+    from weed_instance_segmentation_amd.loss import ReplayPointProvider
+    g, cfg, model, _ = tiny
+    B = g["pixel_values"].shape[0]
+    ml, cl = _labels(g, B, dtype=label_dtype)
+    n_layers = cfg.decoder_layers - 1
+    draws = [T(g[f"draw_{i}"]) for i in range(int(g["n_draws"]))][n_layers:]
+    prov = ReplayPointProvider(draws, cfg.decoder_layers, B, "cuda")
+    with torch.no_grad():
+        out = model(pixel_values=T(g["pixel_values"]).cuda(), mask_labels=ml, class_labels=cl, point_provider=prov)
+    for i, (r, c) in enumerate(out.matched_indices):  # bit-exact assignment
+        assert np.array_equal(r.numpy(), g[f"row_{i}"]) and np.array_equal(c.numpy(), g[f"col_{i}"])
+    for k, v in out.loss_dict.items():
+        torch.testing.assert_close(v.cpu(), T(g["ld." + k]), rtol=2e-3, atol=1e-4)
+    torch.testing.assert_close(out.loss.cpu(), T(g["loss"]), rtol=1e-3, atol=1e-3)
+
+
+def test_forward_matches_oracle_other_input(tiny):
+    """Different input than the fixture: the oracle is the checker (same weights)."""
+    g, cfg, model, sd = tiny
+    x = torch.randn(3, 3, 96, 64, generator=torch.Generator().manual_seed(5))
+    res = O.forward(sd, json.loads(str(g["config_json"])), x)
+    with torch.no_grad():
+        out = model(pixel_values=x.cuda())
+    ref = res["masks_queries_logits"]
+    assert (out.masks_queries_logits.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+    torch.testing.assert_close(out.class_queries_logits.cpu(), res["class_queries_logits"], rtol=1e-3, atol=1e-3)
+
+
+def test_train_step_backward_runs(tiny):
+    """Gradients flow through K1 (HIP backward), K3 and the point sampler; cross-attention backward is
+    exercised once its kernel exists."""
+    g, cfg, model, _ = tiny
+    from weed_instance_segmentation_amd import Mask2FormerForUniversalSegmentation
+    m = Mask2FormerForUniversalSegmentation(cfg).cuda().train()
+    B = g["pixel_values"].shape[0]
+    ml, cl = _labels(g, B)
+    try:
+        out = m(pixel_values=T(g["pixel_values"]).cuda(), mask_labels=ml, class_labels=cl)
+        out.loss.backward()
+    except NotImplementedError as e:
+        pytest.xfail(str(e))
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert len(grads) > 100 and all(torch.isfinite(gr).all() for gr in grads)

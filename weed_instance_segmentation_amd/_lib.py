@@ -32,8 +32,8 @@ SIGNATURES = {
     "wm2f_matcher_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_matcher_cost": (c_int, [_P, _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                   c_float, c_float, c_float, _P]),
-    "wm2f_point_sample_fwd": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "wm2f_point_sample_bwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "wm2f_point_sample_fwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "wm2f_point_sample_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

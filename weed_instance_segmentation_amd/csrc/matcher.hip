@@ -35,25 +35,28 @@ __device__ __forceinline__ float bilinear_zeros(const T* __restrict__ img, int H
   return r;
 }
 
-// out[n][p] = bilinear(feat[n], pts[n][p])          grid (ceil(P/256), N)
+// out[m][p] = bilinear(feat[map_index ? map_index[m] : m], pts[m][p])          grid (ceil(P/256), M)
 template <typename T>
 __global__ __launch_bounds__(256) void point_sample_fwd_kernel(const T* __restrict__ feat,
                                                                const float* __restrict__ pts,
-                                                               float* __restrict__ out, int H, int W, int P,
-                                                               int64_t pts_stride_n) {
-  const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+                                                               const int32_t* __restrict__ map_index,
+                                                               float* __restrict__ out, int H, int W, int P) {
+  const int p = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
   if (p >= P) return;
-  const float* pp = pts + n * pts_stride_n + (int64_t)p * 2;
-  out[(int64_t)n * P + p] = bilinear_zeros(feat + (int64_t)n * H * W, H, W, pp[0], pp[1]);
+  const int64_t src = map_index ? map_index[m] : m;
+  const float* pp = pts + ((int64_t)m * P + p) * 2;
+  out[(int64_t)m * P + p] = bilinear_zeros(feat + src * H * W, H, W, pp[0], pp[1]);
 }
 
 __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __restrict__ grad_out,
                                                                const float* __restrict__ pts,
+                                                               const int32_t* __restrict__ map_index,
                                                                float* __restrict__ grad_feat, int H, int W, int P) {
-  const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
   if (p >= P) return;
-  const float* pp = pts + ((int64_t)n * P + p) * 2;
-  const float go = grad_out[(int64_t)n * P + p];
+  const int64_t n = map_index ? map_index[m] : m;
+  const float* pp = pts + ((int64_t)m * P + p) * 2;
+  const float go = grad_out[(int64_t)m * P + p];
   const float gx = 2.f * pp[0] - 1.f, gy = 2.f * pp[1] - 1.f;
   const float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
   const float y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void point_sample_bwd_kernel(const float* __re
   const int x0 = (int)x0f, y0 = (int)y0f;
   const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
   const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
-  float* g = grad_feat + (int64_t)n * H * W + (int64_t)y0 * W + x0;
+  float* g = grad_feat + n * H * W + (int64_t)y0 * W + x0;
   if (yt && xl) atomicAdd(g, go * fx0 * fy0);
   if (yt && xr) atomicAdd(g + 1, go * fx1 * fy0);
   if (yb && xl) atomicAdd(g + W, go * fx0 * fy1);
@@ -255,30 +258,30 @@ extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logi
   return WM2F_OK;
 }
 
-extern "C" int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, void* out, int N, int H,
-                                     int W, int P, void* stream) {
+extern "C" int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, const void* map_index,
+                                     void* out, int M, int H, int W, int P, void* stream) {
   const char* who = "wm2f_point_sample_fwd";
   WM2F_REQUIRE(feat && pts && out, "%s: null pointer", who);
-  WM2F_REQUIRE(N > 0 && H > 0 && W > 0 && P > 0 && N <= 65535, "%s: bad size", who);
+  WM2F_REQUIRE(M > 0 && H > 0 && W > 0 && P > 0 && M <= 65535, "%s: bad size", who);
   WM2F_REQUIRE(feat_dtype == 0 || feat_dtype == 1, "%s: feat_dtype must be 0 (fp32) or 1 (uint8)", who);
-  dim3 grid(ceil_div(P, 256), N);
+  dim3 grid(ceil_div(P, 256), M);
   if (feat_dtype == 0)
     hipLaunchKernelGGL(point_sample_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)feat,
-                       (const float*)pts, (float*)out, H, W, P, (int64_t)P * 2);
+                       (const float*)pts, (const int32_t*)map_index, (float*)out, H, W, P);
   else
     hipLaunchKernelGGL(point_sample_fwd_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)feat, (const float*)pts, (float*)out, H, W, P, (int64_t)P * 2);
+                       (const uint8_t*)feat, (const float*)pts, (const int32_t*)map_index, (float*)out, H, W, P);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
 
-extern "C" int wm2f_point_sample_bwd(const void* grad_out, const void* pts, void* grad_feat, int N, int H, int W,
-                                     int P, void* stream) {
+extern "C" int wm2f_point_sample_bwd(const void* grad_out, const void* pts, const void* map_index, void* grad_feat,
+                                     int M, int H, int W, int P, void* stream) {
   const char* who = "wm2f_point_sample_bwd";
   WM2F_REQUIRE(grad_out && pts && grad_feat, "%s: null pointer", who);
-  WM2F_REQUIRE(N > 0 && H > 0 && W > 0 && P > 0 && N <= 65535, "%s: bad size", who);
-  hipLaunchKernelGGL(point_sample_bwd_kernel, dim3(ceil_div(P, 256), N), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)grad_out, (const float*)pts, (float*)grad_feat, H, W, P);
+  WM2F_REQUIRE(M > 0 && H > 0 && W > 0 && P > 0 && M <= 65535, "%s: bad size", who);
+  hipLaunchKernelGGL(point_sample_bwd_kernel, dim3(ceil_div(P, 256), M), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)grad_out, (const float*)pts, (const int32_t*)map_index, (float*)grad_feat, H, W, P);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }

@@ -1,0 +1,190 @@
+"""Hungarian matcher + Mask2Former loss on the GPU.
+
+Mirrors `Mask2FormerHungarianMatcher` (HF:378-481) and `Mask2FormerLoss` (HF:485-794):
+same sampling scheme, same weights, same result, but organised for one MI355X per process:
+
+  * the cost matrices of EVERY prediction level and EVERY image come from one batched kernel
+    call (K4, ops.matcher_cost) and reach the host in ONE copy; the reference syncs once per
+    (image, level) -- B x 10 times per step (HF:474);
+  * the linear-sum-assignment solver stays scipy on the host, exactly as in the reference;
+  * point sampling of predictions / targets uses the HIP sampler (ops.point_sample).
+
+Random points: the dependency draws from torch's global generator in call order (HF:455, :705,
+:721).  Here a `point_provider` supplies them by ROLE, so tests can replay recorded draws;
+the default provider draws on the device.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from . import ops
+
+
+class DevicePointProvider:
+    """Default: fresh uniform points on the device.  `level` counts prediction levels in decoder order."""
+
+    def __init__(self, device, generator: torch.Generator | None = None):
+        self.device, self.generator = device, generator
+
+    def _rand(self, *shape):
+        return torch.rand(*shape, device=self.device, generator=self.generator)
+
+    def matcher_points(self, n_levels: int, batch: int, num_points: int) -> torch.Tensor:
+        return self._rand(n_levels, batch, num_points, 2)
+
+    def oversample_points(self, level: int, n_masks: int, n: int) -> torch.Tensor:
+        return self._rand(n_masks, n, 2)
+
+    def random_points(self, level: int, n_masks: int, n: int) -> torch.Tensor:
+        return self._rand(n_masks, n, 2)
+
+
+class ReplayPointProvider:
+    """Replays draws recorded from the dependency (tests): its order is, per criterion call
+    (final level first, then auxiliary levels 0..n-2): B matcher draws (1,P,2), one oversample
+    draw (M,3P,2), one random draw (M,P/4,2)."""
+
+    def __init__(self, draws: Sequence[torch.Tensor], n_levels: int, batch: int, device):
+        self.draws, self.n_levels, self.batch, self.device = list(draws), n_levels, batch, device
+        self.per_level = batch + 2
+
+    def _slot(self, level: int) -> int:
+        order = [self.n_levels - 1] + list(range(self.n_levels - 1))
+        return order.index(level) * self.per_level
+
+    def matcher_points(self, n_levels, batch, num_points):
+        out = [torch.cat([self.draws[self._slot(l) + b] for b in range(batch)], 0) for l in range(n_levels)]
+        return torch.stack(out).to(self.device)
+
+    def oversample_points(self, level, n_masks, n):
+        return self.draws[self._slot(level) + self.batch].to(self.device)
+
+    def random_points(self, level, n_masks, n):
+        return self.draws[self._slot(level) + self.batch + 1].to(self.device)
+
+
+class Mask2FormerLoss(nn.Module):
+    def __init__(self, config, weight_dict):
+        super().__init__()
+        self.num_labels = config.num_labels
+        self.weight_dict = weight_dict
+        self.eos_coef = config.no_object_weight
+        ew = torch.ones(self.num_labels + 1)
+        ew[-1] = self.eos_coef
+        self.register_buffer("empty_weight", ew)
+        self.num_points = config.train_num_points
+        self.oversample_ratio = config.oversample_ratio
+        self.importance_sample_ratio = config.importance_sample_ratio
+        self.cost_class, self.cost_mask, self.cost_dice = config.class_weight, config.mask_weight, config.dice_weight
+        self.world_size_fn = None  # set by parallel.DataParallelEngine: all-reduces num_masks (HF:781-794)
+
+    # ---------------------------------------------------------------- matcher (all levels at once)
+    @torch.no_grad()
+    def match(self, all_masks, all_classes, tgt, counts, cls, points):
+        """Returns indices[level][image] = (rows int64, cols int64) -- HF:413-481."""
+        NL, B = len(all_masks), all_masks[0].shape[0]
+        if sum(counts) == 0:
+            e = torch.zeros(0, dtype=torch.int64)
+            return [[(e, e) for _ in range(B)] for _ in range(NL)]
+        ml = torch.stack([m.detach() for m in all_masks]) if NL > 1 else all_masks[0].detach()[None]
+        cl = torch.stack([c.detach() for c in all_classes]) if NL > 1 else all_classes[0].detach()[None]
+        cost = ops.matcher_cost(ml.float(), cl.float(), tgt, counts, cls, points, self.cost_class, self.cost_mask,
+                                self.cost_dice)
+        cost = cost.cpu().numpy()  # the ONE device->host sync of the step
+        indices = []
+        for l in range(NL):
+            per = []
+            for b in range(B):
+                r, c = linear_sum_assignment(cost[l, b, :, :counts[b]])
+                per.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(c, dtype=torch.int64)))
+            indices.append(per)
+        return indices
+
+    # ---------------------------------------------------------------- per-level losses
+    def _num_masks(self, counts, device):
+        n = torch.as_tensor(float(sum(counts)), dtype=torch.float, device=device)
+        world = 1
+        if self.world_size_fn is not None:
+            n, world = self.world_size_fn(n)
+        return torch.clamp(n / world, min=1)
+
+    def loss_labels(self, classes, cls, offsets, indices):
+        """HF:546-578."""
+        B, Q, _ = classes.shape
+        dev = classes.device
+        bi = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(indices)]).to(dev)
+        si = torch.cat([s for s, _ in indices]).to(dev)
+        ti = torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices)]).to(dev)
+        target = torch.full((B, Q), self.num_labels, dtype=torch.int64, device=dev)
+        target[bi, si] = cls[ti]
+        return F.cross_entropy(classes.transpose(1, 2), target, weight=self.empty_weight)
+
+    def loss_masks(self, masks, tgt, offsets, indices, num_masks, level, provider):
+        """HF:580-640 with the uncertainty sampling of HF:671-724.  Matched prediction and target
+        maps are sampled IN PLACE through an index (no (M,H,W) gathered copies, HF:602-609)."""
+        dev = masks.device
+        B, Q, h, w = masks.shape
+        pred_idx = torch.cat([s + i * Q for i, (s, _) in enumerate(indices)]).to(device=dev, dtype=torch.int32)
+        tgt_idx = torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices)]).to(device=dev, dtype=torch.int32)
+        M, P = int(pred_idx.shape[0]), self.num_points
+        if M == 0:
+            z = masks.sum() * 0.0
+            return z, z
+        maps = masks.reshape(B * Q, h, w).float()
+        n_over = int(P * self.oversample_ratio)
+        n_unc = int(self.importance_sample_ratio * P)
+        with torch.no_grad():
+            pc = provider.oversample_points(level, M, n_over)
+            unc = -ops.point_sample(maps.detach(), pc, pred_idx).abs()
+            idx = torch.topk(unc, k=n_unc, dim=1)[1]
+            pts = torch.gather(pc, 1, idx[..., None].expand(-1, -1, 2))
+            if P - n_unc > 0:
+                pts = torch.cat([pts, provider.random_points(level, M, P - n_unc)], 1)
+            pts = pts.contiguous()
+            point_labels = ops.point_sample(tgt, pts, tgt_idx)
+        point_logits = ops.point_sample(maps, pts, pred_idx)
+        bce = F.binary_cross_entropy_with_logits(point_logits, point_labels, reduction="none")
+        loss_mask = bce.mean(1).sum() / num_masks  # HF:308-324
+        probs = point_logits.sigmoid()
+        num = 2 * (probs * point_labels).sum(-1)
+        den = probs.sum(-1) + point_labels.sum(-1)
+        loss_dice = (1 - (num + 1) / (den + 1)).sum() / num_masks  # HF:278-305
+        return loss_mask, loss_dice
+
+    def forward(self, all_masks, all_classes, mask_labels, class_labels, point_provider=None):
+        """all_masks / all_classes: per-level lists in decoder order, LAST = final prediction.
+        Returns (weighted loss dict with the dependency's key names, indices of the final level)."""
+        NL, B = len(all_masks), all_masks[0].shape[0]
+        dev = all_masks[0].device
+        provider = point_provider or DevicePointProvider(dev)
+        counts = [int(m.shape[0]) for m in mask_labels]
+        offsets = [0]
+        for c in counts:
+            offsets.append(offsets[-1] + c)
+        if len({tuple(m.shape[1:]) for m in mask_labels}) != 1:
+            raise NotImplementedError("mask_labels of different sizes in one batch (collate_fn stacks equal sizes)")
+        tgt = torch.cat([m.to(dev) for m in mask_labels], 0)  # once per step, shared by matcher and every level
+        if tgt.dtype == torch.bool:
+            tgt = tgt.view(torch.uint8)
+        elif tgt.dtype not in (torch.uint8, torch.float32):
+            tgt = tgt.float()
+        cls = torch.cat([c.to(dev) for c in class_labels], 0).to(torch.int64)
+        points = provider.matcher_points(NL, B, self.num_points)
+        indices = self.match(all_masks, all_classes, tgt, counts, cls, points)
+        num_masks = self._num_masks(counts, dev)
+        losses = {}
+        order = [NL - 1] + list(range(NL - 1))  # HF:762-777: final level first, then aux 0..n-2
+        for n, lvl in enumerate(order):
+            lm, ld = self.loss_masks(all_masks[lvl], tgt, offsets, indices[lvl], num_masks, lvl, provider)
+            lc = self.loss_labels(all_classes[lvl], cls, offsets, indices[lvl])
+            suffix = "" if n == 0 else f"_{lvl}"
+            losses["loss_mask" + suffix] = lm * self.weight_dict["loss_mask"]
+            losses["loss_dice" + suffix] = ld * self.weight_dict["loss_dice"]
+            losses["loss_cross_entropy" + suffix] = lc * self.weight_dict["loss_cross_entropy"]
+        return losses, indices[NL - 1]

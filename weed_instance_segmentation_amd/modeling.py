@@ -1,0 +1,511 @@
+"""Drop-in `Mask2FormerForUniversalSegmentation` for the reference's train / eval glue.
+
+Boundary: the reference calls
+    model(pixel_values=..., mask_labels=[...], class_labels=[...]).loss      train.py:28-33, :196-198
+    model(pixel_values=...) -> .class_queries_logits, .masks_queries_logits   metrics.py:56-63, inference.py:25-30
+    .to(device) .train() .eval() .parameters() .config.id2label                train.py:173-178, model_utils.py:16
+    .save_pretrained(dir) / .from_pretrained(local_dir, id2label=..., label2id=..., ignore_mismatched_sizes=True)
+on the class of the same name in `transformers`.  This module keeps that call contract and that
+class's parameter names (so checkpoints round-trip), and routes the four hot operations to the
+hand-written HIP kernels in libwm2f.so through `ops`:
+    K1 ops.ms_deform_attn[_fused]   (HF:798-837, :983-1002)
+    K2 ops.masked_xattn             (HF:1644-1650, :1912-1914)
+    K3 ops.mask_einsum + ops.attn_mask_build (HF:2046-2054)
+    K4 ops.matcher_cost             (HF:444-472)            -- in loss.py
+There is no CPU path: tensors must live on an MI355X.  Everything else (backbone convolutions,
+1x1 convs, GroupNorm, LayerNorm, Linear) is stock PyTorch-ROCm.
+
+Internal layout is batch-first (B, tokens, C) everywhere; the dependency's sequence-first layout
+(HF:2099-2101) is not reproduced because nothing at the boundary exposes it.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .backbone_resnet import build_backbone
+from .configuration import Mask2FormerConfig
+from .loss import Mask2FormerLoss
+
+
+class Mask2FormerForUniversalSegmentationOutput:
+    """Attribute- and key-addressable result, same field names as HF:196-241."""
+
+    _fields = ("loss", "class_queries_logits", "masks_queries_logits", "auxiliary_logits", "encoder_last_hidden_state",
+               "pixel_decoder_last_hidden_state", "transformer_decoder_last_hidden_state", "encoder_hidden_states",
+               "pixel_decoder_hidden_states", "transformer_decoder_hidden_states", "attentions")
+
+    def __init__(self, **kw):
+        for f in self._fields:
+            setattr(self, f, kw.get(f))
+        self.loss_dict = kw.get("loss_dict")
+        self.matched_indices = kw.get("matched_indices")
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return self.to_tuple()[k]
+
+    def keys(self):
+        return [f for f in self._fields if getattr(self, f) is not None]
+
+    def to_tuple(self):
+        return tuple(getattr(self, f) for f in self.keys())
+
+
+_POS_CACHE: dict = {}
+
+
+def sine_position_embedding(H: int, W: int, num_pos_feats: int, device, dtype=torch.float32, temperature=10000):
+    """HF:864-904 (normalize=True, scale=2*pi, no mask) for ONE image: (num_pos_feats*2, H, W).
+    Identical for every image of a batch, so it is built once per (shape, device) and cached."""
+    key = (H, W, num_pos_feats, str(device), dtype)
+    if key not in _POS_CACHE:
+        scale, eps = 2 * math.pi, 1e-6
+        y = torch.arange(1, H + 1, dtype=dtype, device=device)[:, None].expand(H, W)
+        x = torch.arange(1, W + 1, dtype=dtype, device=device)[None, :].expand(H, W)
+        y = y / (y[-1:, :] + eps) * scale
+        x = x / (x[:, -1:] + eps) * scale
+        dim_t = torch.arange(num_pos_feats, dtype=torch.int64, device=device).to(dtype)
+        dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+        px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+        px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=3).flatten(2)
+        py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=3).flatten(2)
+        _POS_CACHE[key] = torch.cat((py, px), dim=2).permute(2, 0, 1).contiguous()
+    return _POS_CACHE[key]
+
+
+# ------------------------------------------------------------------------------ pixel decoder
+class MSDeformAttn(nn.Module):
+    """Mask2FormerPixelDecoderEncoderMultiscaleDeformableAttention, HF:919-1014."""
+
+    def __init__(self, embed_dim: int, num_heads: int, n_levels: int = 3, n_points: int = 4):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise ValueError(f"embed_dim {embed_dim} not divisible by num_heads {num_heads}")
+        self.d_model, self.n_heads, self.n_levels, self.n_points = embed_dim, num_heads, n_levels, n_points
+        self.sampling_offsets = nn.Linear(embed_dim, num_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(embed_dim, num_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(embed_dim, embed_dim)
+        self.output_proj = nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, hidden, pos, ref, level_hw):
+        """hidden, pos (B,S,C); ref (S,L,2) reference points shared by the batch."""
+        B, S, C = hidden.shape
+        H, L, P = self.n_heads, self.n_levels, self.n_points
+        hp = hidden + pos
+        value = self.value_proj(hidden).view(B, S, H, C // H)
+        off = self.sampling_offsets(hp).view(B, S, H, L, P, 2)
+        logits = self.attention_weights(hp).view(B, S, H, L * P)
+        if torch.is_grad_enabled() and (hidden.requires_grad or self.value_proj.weight.requires_grad):
+            norm = torch.tensor([[w, h] for h, w in level_hw], dtype=hidden.dtype, device=hidden.device)
+            loc = ref[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+            aw = torch.softmax(logits, -1).view(B, S, H, L, P)
+            out = ops.ms_deform_attn(value, level_hw, loc, aw)
+        else:  # inference: softmax + location arithmetic fused into the kernel prologue
+            out = ops.ms_deform_attn_fused(value, level_hw, off, logits, ref)
+        return self.output_proj(out)
+
+
+class PixelDecoderEncoderLayer(nn.Module):
+    """HF:1017-1103 (post-norm; dropout is 0.0 in every published configuration)."""
+
+    def __init__(self, config: Mask2FormerConfig):
+        super().__init__()
+        d = config.feature_size
+        self.self_attn = MSDeformAttn(d, config.num_attention_heads, 3, 4)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.dropout = config.dropout
+        self.fc1 = nn.Linear(d, config.encoder_feedforward_dim)
+        self.fc2 = nn.Linear(config.encoder_feedforward_dim, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+    def forward(self, hidden, pos, ref, level_hw):
+        a = F.dropout(self.self_attn(hidden, pos, ref, level_hw), self.dropout, self.training)
+        hidden = self.self_attn_layer_norm(hidden + a)
+        f = F.dropout(F.relu(self.fc1(hidden)), self.dropout, self.training)
+        f = F.dropout(self.fc2(f), self.dropout, self.training)
+        hidden = self.final_layer_norm(hidden + f)
+        if self.training and not torch.isfinite(hidden).all():  # HF:1090-1093
+            cv = torch.finfo(hidden.dtype).max - 1000
+            hidden = torch.clamp(hidden, min=-cv, max=cv)
+        return hidden
+
+
+class PixelDecoderEncoderOnly(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layers = nn.ModuleList([PixelDecoderEncoderLayer(config) for _ in range(config.encoder_layers)])
+
+    @staticmethod
+    def reference_points(level_hw, device, dtype=torch.float32):
+        """HF:1127-1156 with valid ratios of 1 (HF:1343-1345 builds all-False padding masks): (S, L, 2)."""
+        pts = []
+        for h, w in level_hw:
+            ry, rx = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, dtype=dtype, device=device),
+                                    torch.linspace(0.5, w - 0.5, w, dtype=dtype, device=device), indexing="ij")
+            pts.append(torch.stack((rx.reshape(-1) / w, ry.reshape(-1) / h), -1))
+        ref = torch.cat(pts, 0)
+        return ref[:, None, :].expand(-1, len(level_hw), -1).contiguous()
+
+    def forward(self, hidden, pos, level_hw):
+        ref = self.reference_points(level_hw, hidden.device, hidden.dtype)
+        for layer in self.layers:
+            hidden = layer(hidden, pos, ref, level_hw)
+        return hidden
+
+
+class Mask2FormerPixelDecoder(nn.Module):
+    """HF:1236-1419."""
+
+    def __init__(self, config: Mask2FormerConfig, feature_channels: Sequence[int]):
+        super().__init__()
+        self.config = config
+        d, md = config.feature_size, config.mask_feature_size
+        self.num_feature_levels = 3
+        tin = list(feature_channels[-3:])
+        self.level_embed = nn.Parameter(torch.zeros(3, d))
+        self.input_projections = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(c, d, kernel_size=1), nn.GroupNorm(32, d)) for c in tin[::-1]])
+        self.encoder = PixelDecoderEncoderOnly(config)
+        self.mask_projection = nn.Conv2d(d, md, kernel_size=1)
+        stride = min(config.feature_strides[-3:])
+        self.num_fpn_levels = int(np.log2(stride) - np.log2(config.common_stride))
+        for idx, c in enumerate(feature_channels[: self.num_fpn_levels]):
+            self.add_module(f"adapter_{idx + 1}", nn.Sequential(nn.Conv2d(c, d, kernel_size=1, bias=False), nn.GroupNorm(32, d)))
+            self.add_module(f"layer_{idx + 1}", nn.Sequential(nn.Conv2d(d, d, kernel_size=3, padding=1, bias=False),
+                                                              nn.GroupNorm(32, d), nn.ReLU()))
+
+    def forward(self, features: Sequence[torch.Tensor]):
+        d = self.config.feature_size
+        embeds, poss = [], []
+        for lvl, x in enumerate(features[::-1][:3]):
+            embeds.append(self.input_projections[lvl](x))
+            pe = sine_position_embedding(x.shape[2], x.shape[3], d // 2, x.device, x.dtype)
+            poss.append(pe.flatten(1).transpose(0, 1) + self.level_embed[lvl][None, :])  # (HW, C)
+        level_hw = [(int(e.shape[2]), int(e.shape[3])) for e in embeds]
+        B = embeds[0].shape[0]
+        hidden = torch.cat([e.flatten(2).transpose(1, 2) for e in embeds], 1)
+        pos = torch.cat(poss, 0)[None].expand(B, -1, -1)
+        hidden = self.encoder(hidden, pos, level_hw)
+        outs, start = [], 0
+        for h, w in level_hw:
+            outs.append(hidden[:, start:start + h * w].transpose(1, 2).reshape(B, d, h, w))
+            start += h * w
+        n = self.num_fpn_levels
+        for idx, feat in enumerate(features[:n][::-1]):  # HF:1395-1405
+            k = n - idx
+            lat = getattr(self, f"adapter_{k}")(feat)
+            out = lat + F.interpolate(outs[-1], size=lat.shape[-2:], mode="bilinear", align_corners=False)
+            outs.append(getattr(self, f"layer_{k}")(out))
+        return self.mask_projection(outs[-1]), outs[:3]
+
+
+class Mask2FormerPixelLevelModule(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.encoder = build_backbone(config.backbone_config)
+        self.decoder = Mask2FormerPixelDecoder(config, self.encoder.channels)
+
+    def forward(self, pixel_values):
+        feats = self.encoder(pixel_values)
+        mask_features, multi_scale = self.decoder(feats)
+        return feats, mask_features, multi_scale
+
+
+# ------------------------------------------------------------------------------ transformer decoder
+class SelfAttention(nn.Module):
+    """Mask2FormerAttention, HF:1451-1584 (100 x 100 dense attention; stock ops, out of kernel scope)."""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.scaling = self.head_dim ** -0.5
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, h, qpos):
+        B, Q, E = h.shape
+        hq = h + qpos
+        sh = lambda t: t.view(B, Q, self.num_heads, self.head_dim).transpose(1, 2)
+        q, k, v = sh(self.q_proj(hq) * self.scaling), sh(self.k_proj(hq)), sh(self.v_proj(h))
+        a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)), -1)
+        return self.out_proj(torch.matmul(a, v).transpose(1, 2).reshape(B, Q, E))
+
+
+class _OutProj(nn.Linear):
+    pass
+
+
+class MaskedCrossAttention(nn.Module):
+    """nn.MultiheadAttention as used at HF:1618, :1644-1650, with the same parameter names
+    (in_proj_weight, in_proj_bias, out_proj.*); the attention itself is kernel K2."""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = _OutProj(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+    def project_kv(self, key_in, value_in):
+        E = self.embed_dim
+        k = F.linear(key_in, self.in_proj_weight[E:2 * E], self.in_proj_bias[E:2 * E])
+        v = F.linear(value_in, self.in_proj_weight[2 * E:], self.in_proj_bias[2 * E:])
+        return k, v
+
+    def forward(self, query_in, k, v, mask, row_open):
+        E = self.embed_dim
+        q = F.linear(query_in, self.in_proj_weight[:E], self.in_proj_bias[:E]) * (1.0 / math.sqrt(self.head_dim))
+        ctx = ops.masked_xattn(q, k, v, mask, row_open, self.num_heads)
+        return self.out_proj(ctx)
+
+
+class MaskedAttentionDecoderLayer(nn.Module):
+    """HF:1587-1797."""
+
+    def __init__(self, config):
+        super().__init__()
+        d = config.hidden_dim
+        self.pre_norm, self.dropout = config.pre_norm, config.dropout
+        if config.activation_function != "relu":
+            raise NotImplementedError("activation_function other than relu")
+        self.self_attn = SelfAttention(d, config.num_attention_heads)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.cross_attn = MaskedCrossAttention(d, config.num_attention_heads)
+        self.cross_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, config.dim_feedforward)
+        self.fc2 = nn.Linear(config.dim_feedforward, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+    def forward(self, h, qpos, k, v, mask, row_open):
+        drop = lambda t: F.dropout(t, self.dropout, self.training)
+        if not self.pre_norm:  # forward_post, HF:1636-1690
+            h = self.cross_attn_layer_norm(h + drop(self.cross_attn(h + qpos, k, v, mask, row_open)))
+            h = self.self_attn_layer_norm(h + drop(self.self_attn(h, qpos)))
+            f = drop(self.fc2(drop(F.relu(self.fc1(h)))))
+            return self.final_layer_norm(h + f)
+        x = self.cross_attn_layer_norm(h)  # forward_pre, HF:1692-1750
+        h = h + drop(self.cross_attn(x + qpos, k, v, mask, row_open))
+        h = h + drop(self.self_attn(self.self_attn_layer_norm(h), qpos))
+        x = self.final_layer_norm(h)
+        return h + drop(self.fc2(drop(F.relu(self.fc1(x)))))
+
+
+def _mlp_head(din, dh, dout, n=3):
+    """Mask2FormerMLPPredictionHead (HF:1979-2015): names '<i>.0.weight'."""
+    dims = [din] + [dh] * (n - 1) + [dout]
+    return nn.Sequential(*[nn.Sequential(nn.Linear(a, b), nn.ReLU() if i < n - 1 else nn.Identity())
+                           for i, (a, b) in enumerate(zip(dims[:-1], dims[1:]))])
+
+
+class MaskPredictor(nn.Module):
+    """HF:2018-2056: MLP, K3 einsum, attention-mask build (un-replicated bytes + row flags)."""
+
+    def __init__(self, hidden, heads, mask_feature_size):
+        super().__init__()
+        self.mask_embedder = _mlp_head(hidden, hidden, mask_feature_size)
+
+    def forward(self, h_norm, mask_features, next_size):
+        logits = ops.mask_einsum(self.mask_embedder(h_norm), mask_features)
+        mask, row_open = ops.attn_mask_build(logits, next_size)
+        return logits, mask, row_open
+
+
+class MaskedAttentionDecoder(nn.Module):
+    """HF:1801-1960."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layerdrop = config.dropout
+        self.layers = nn.ModuleList([MaskedAttentionDecoderLayer(config) for _ in range(config.decoder_layers - 1)])
+        self.layernorm = nn.LayerNorm(config.hidden_dim)
+        self.mask_predictor = MaskPredictor(config.hidden_dim, config.num_attention_heads, config.mask_feature_size)
+
+    def forward(self, h, qpos, feats, poss, mask_features, sizes):
+        inter = [self.layernorm(h)]
+        logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0])
+        all_logits = [logits]
+        for idx, layer in enumerate(self.layers):
+            if self.training and self.layerdrop > 0 and float(torch.rand([])) < self.layerdrop:  # HF:1905-1908
+                continue
+            lvl = idx % 3
+            k, v = layer.cross_attn.project_kv(feats[lvl] + poss[lvl], feats[lvl])
+            h = layer(h, qpos, k, v, mask, row_open)
+            inter.append(self.layernorm(h))
+            logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[(idx + 1) % 3])
+            all_logits.append(logits)
+        return h, inter, all_logits
+
+
+class Mask2FormerTransformerModule(nn.Module):
+    """HF:2059-2129."""
+
+    def __init__(self, in_features, config):
+        super().__init__()
+        d = config.hidden_dim
+        self.config = config
+        self.queries_embedder = nn.Embedding(config.num_queries, d)
+        self.queries_features = nn.Embedding(config.num_queries, d)
+        # The dependency keeps these projections in a plain Python list (HF:2073-2079): they are NOT
+        # registered, never saved and never trained.  With in_features == hidden_dim they are identity.
+        if in_features != d or config.enforce_input_projection:
+            raise NotImplementedError("feature_size != hidden_dim / enforce_input_projection: the dependency's "
+                                      "unregistered input projections are not reproduced")
+        self.decoder = MaskedAttentionDecoder(config)
+        self.level_embed = nn.Embedding(3, d)
+
+    def forward(self, multi_scale, mask_features):
+        d = self.config.hidden_dim
+        B = mask_features.shape[0]
+        feats, poss, sizes = [], [], []
+        for i in range(3):
+            f = multi_scale[i]
+            sizes.append((int(f.shape[2]), int(f.shape[3])))
+            pe = sine_position_embedding(f.shape[2], f.shape[3], d // 2, f.device, f.dtype)
+            poss.append(pe.flatten(1).transpose(0, 1)[None])  # (1, HW, C)
+            feats.append(f.flatten(2).transpose(1, 2) + self.level_embed.weight[i][None, None, :])  # (B, HW, C)
+        qpos = self.queries_embedder.weight[None].expand(B, -1, -1)
+        h = self.queries_features.weight[None].expand(B, -1, -1)
+        return self.decoder(h, qpos, feats, poss, mask_features, sizes)
+
+
+class Mask2FormerModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.pixel_level_module = Mask2FormerPixelLevelModule(config)
+        self.transformer_module = Mask2FormerTransformerModule(config.feature_size, config)
+
+
+# ------------------------------------------------------------------------------ top level
+class Mask2FormerForUniversalSegmentation(nn.Module):
+    """HF:2278-2530.  See the module docstring for the call contract."""
+
+    main_input_name = "pixel_values"
+    config_class = Mask2FormerConfig
+
+    def __init__(self, config: Mask2FormerConfig):
+        super().__init__()
+        self.config = config
+        self.model = Mask2FormerModel(config)
+        self.weight_dict = {"loss_cross_entropy": config.class_weight, "loss_mask": config.mask_weight,
+                            "loss_dice": config.dice_weight}
+        self.class_predictor = nn.Linear(config.hidden_dim, config.num_labels + 1)
+        self.criterion = Mask2FormerLoss(config, self.weight_dict)
+        self.apply(self._init_weights)
+
+    # -- initialisation, HF:2139-2199 ------------------------------------------------------
+    def _init_weights(self, m):
+        cfg = self.config
+        if isinstance(m, MSDeformAttn):
+            nn.init.constant_(m.sampling_offsets.weight, 0.0)
+            thetas = torch.arange(m.n_heads, dtype=torch.int64).float() * (2.0 * math.pi / m.n_heads)
+            grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+            grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(m.n_heads, 1, 1, 2).repeat(1, m.n_levels, m.n_points, 1)
+            for i in range(m.n_points):
+                grid[:, :, i, :] *= i + 1
+            with torch.no_grad():
+                m.sampling_offsets.bias.copy_(grid.view(-1))
+            nn.init.constant_(m.attention_weights.weight, 0.0)
+            nn.init.constant_(m.attention_weights.bias, 0.0)
+            nn.init.xavier_uniform_(m.value_proj.weight)
+            nn.init.constant_(m.value_proj.bias, 0.0)
+            nn.init.xavier_uniform_(m.output_proj.weight)
+            nn.init.constant_(m.output_proj.bias, 0.0)
+        elif isinstance(m, MaskedAttentionDecoderLayer):
+            for p in m.parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p, gain=cfg.init_xavier_std)
+            nn.init.zeros_(m.cross_attn.in_proj_bias)
+        elif isinstance(m, Mask2FormerPixelDecoder):
+            nn.init.zeros_(m.level_embed)
+        elif isinstance(m, (nn.Linear, nn.Conv2d)) and not isinstance(m, _OutProj):
+            pass  # torch defaults (kaiming-uniform), as the dependency leaves them unless listed above
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, mean=0.0, std=1.0)
+
+    # -- forward, HF:2332-2530 -------------------------------------------------------------
+    def forward(self, pixel_values: torch.Tensor, mask_labels=None, class_labels=None, pixel_mask=None,
+                output_hidden_states=None, output_auxiliary_logits=None, output_attentions=None, return_dict=None,
+                point_provider=None, **kwargs):
+        if output_attentions:
+            raise NotImplementedError("output_attentions: attention maps are never materialised by the kernels")
+        feats, mask_features, multi_scale = self.model.pixel_level_module(pixel_values)
+        h, inter, all_logits = self.model.transformer_module(multi_scale, mask_features)
+        all_classes = [self.class_predictor(s) for s in inter]
+        aux = [{"masks_queries_logits": m, "class_queries_logits": c} for m, c in zip(all_logits[:-1], all_classes[:-1])]
+        loss = loss_dict = indices = None
+        if mask_labels is not None and class_labels is not None:
+            use_aux = self.config.use_auxiliary_loss
+            loss_dict, indices = self.criterion(all_logits if use_aux else all_logits[-1:],
+                                                all_classes if use_aux else all_classes[-1:], mask_labels, class_labels,
+                                                point_provider=point_provider)
+            loss = sum(loss_dict.values())
+        want_aux = self.config.output_auxiliary_logits if output_auxiliary_logits is None else output_auxiliary_logits
+        out = Mask2FormerForUniversalSegmentationOutput(
+            loss=loss, class_queries_logits=all_classes[-1], masks_queries_logits=all_logits[-1],
+            auxiliary_logits=aux if want_aux else None, encoder_last_hidden_state=feats[-1],
+            pixel_decoder_last_hidden_state=mask_features, transformer_decoder_last_hidden_state=h,
+            encoder_hidden_states=tuple(feats) if output_hidden_states else None,
+            pixel_decoder_hidden_states=tuple(multi_scale) if output_hidden_states else None,
+            transformer_decoder_hidden_states=tuple(inter) if output_hidden_states else None,
+            loss_dict=loss_dict, matched_indices=indices)
+        if return_dict is False:
+            t = out.to_tuple()
+            return t
+        return out
+
+    # -- persistence: the dependency's on-disk format (config.json + model.safetensors) -----
+    def save_pretrained(self, directory: str, **_):
+        from safetensors.torch import save_file
+        os.makedirs(directory, exist_ok=True)
+        self.config.save_pretrained(directory)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        save_file(sd, os.path.join(directory, "model.safetensors"), metadata={"format": "pt"})
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, id2label=None, label2id=None,
+                        ignore_mismatched_sizes: bool = False, **config_overrides):
+        d = pretrained_model_name_or_path
+        if not os.path.isdir(d):
+            raise FileNotFoundError(
+                f"{d!r} is not a local directory. This build never downloads: pass a directory written by "
+                "save_pretrained (config.json + model.safetensors).")
+        over = dict(config_overrides)
+        if id2label is not None:
+            over["id2label"] = id2label
+            over["label2id"] = label2id
+        config = Mask2FormerConfig.from_pretrained(d, **over)
+        model = cls(config)
+        st_path, bin_path = os.path.join(d, "model.safetensors"), os.path.join(d, "pytorch_model.bin")
+        if os.path.isfile(st_path):
+            from safetensors.torch import load_file
+            sd = load_file(st_path)
+        elif os.path.isfile(bin_path):
+            sd = torch.load(bin_path, map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {d}")
+        own = model.state_dict()
+        mismatched = [k for k, v in sd.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
+        if mismatched and not ignore_mismatched_sizes:
+            raise RuntimeError(f"size mismatch for {mismatched}; pass ignore_mismatched_sizes=True to re-initialise them")
+        for k in mismatched:
+            sd.pop(k)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        missing = [k for k in missing if k not in mismatched]
+        if missing or unexpected:
+            raise RuntimeError(f"checkpoint does not match the module: missing={missing[:8]} unexpected={unexpected[:8]}")
+        model.eval()
+        return model

@@ -15,6 +15,41 @@ from . import _lib
 from ._lib import WM2F_F32, check, host_i32, load
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records: dict[str, list] = {}
+
+    def bracket(self, name, device):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(name, []).append((a, b))
+        return a, b
+
+    def summary(self):
+        """name -> (launches, mean microseconds); call after a device synchronize."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v)) for k, v in self.records.items()}
+
+
+_timer: KernelTimer | None = None
+
+
+def set_kernel_timer(t: KernelTimer | None) -> None:
+    global _timer
+    _timer = t
+
+
+def _timed(name, tensor, fn):
+    if _timer is None:
+        return fn()
+    a, b = _timer.bracket(name, tensor.device)
+    a.record()
+    r = fn()
+    b.record()
+    return r
+
+
 def _p(t: torch.Tensor | None):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -46,8 +81,9 @@ class _MSDeformAttn(torch.autograd.Function):
         out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
         lv = host_i32([x for hw in level_hw for x in hw])
         with torch.cuda.device(value.device):
-            check(load().wm2f_msdeform_fwd(_p(value), _p(loc), _p(attn_w), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32,
-                                           _stream(value)), "wm2f_msdeform_fwd")
+            check(_timed("msdeform_fwd", value, lambda: load().wm2f_msdeform_fwd(
+                _p(value), _p(loc), _p(attn_w), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32, _stream(value))),
+                "wm2f_msdeform_fwd")
         ctx.save_for_backward(value, loc, attn_w)
         ctx.level_hw = tuple(tuple(int(x) for x in hw) for hw in level_hw)
         return out
@@ -90,8 +126,9 @@ def ms_deform_attn_fused(value: torch.Tensor, level_hw, offsets: torch.Tensor, l
     out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
     lv = host_i32([x for hw in level_hw for x in hw])
     with torch.cuda.device(value.device):
-        check(load().wm2f_msdeform_fused_fwd(_p(value), _p(offsets), _p(logits), _p(ref), _p(out), lv, B, S, Q, H, D, L,
-                                             P, WM2F_F32, _stream(value)), "wm2f_msdeform_fused_fwd")
+        check(_timed("msdeform_fused_fwd", value, lambda: load().wm2f_msdeform_fused_fwd(
+            _p(value), _p(offsets), _p(logits), _p(ref), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32, _stream(value))),
+            "wm2f_msdeform_fused_fwd")
     return out
 
 
@@ -106,8 +143,8 @@ class _MaskEinsum(torch.autograd.Function):
         Hh, Ww = pix.shape[2:]
         out = torch.empty(B, Q, Hh, Ww, device=emb.device, dtype=emb.dtype)
         with torch.cuda.device(emb.device):
-            check(load().wm2f_mask_einsum_fwd(_p(emb), _p(pix), _p(out), B, Q, C, Hh * Ww, WM2F_F32, _stream(emb)),
-                  "wm2f_mask_einsum_fwd")
+            check(_timed("mask_einsum_fwd", emb, lambda: load().wm2f_mask_einsum_fwd(
+                _p(emb), _p(pix), _p(out), B, Q, C, Hh * Ww, WM2F_F32, _stream(emb))), "wm2f_mask_einsum_fwd")
         ctx.save_for_backward(emb, pix)
         return out
 
@@ -135,8 +172,8 @@ def attn_mask_build(logits: torch.Tensor, size: Sequence[int]):
     mask = torch.empty(B, Q, Hn * Wn, device=logits.device, dtype=torch.uint8)
     row_open = torch.empty(B, Q, device=logits.device, dtype=torch.int32)
     with torch.cuda.device(logits.device):
-        check(load().wm2f_attn_mask_build(_p(logits), _p(mask), _p(row_open), B, Q, H, W, Hn, Wn, _stream(logits)),
-              "wm2f_attn_mask_build")
+        check(_timed("attn_mask_build", logits, lambda: load().wm2f_attn_mask_build(
+            _p(logits), _p(mask), _p(row_open), B, Q, H, W, Hn, Wn, _stream(logits))), "wm2f_attn_mask_build")
     return mask, row_open
 
 
@@ -161,8 +198,9 @@ class _MaskedXAttn(torch.autograd.Function):
         lib = load()
         ws = torch.empty(int(lib.wm2f_masked_xattn_workspace(B, heads, Q, N, D)), device=q.device, dtype=torch.uint8)
         with torch.cuda.device(q.device):
-            check(lib.wm2f_masked_xattn_fwd(_p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(ws), B,
-                                            heads, Q, N, D, WM2F_F32, _stream(q)), "wm2f_masked_xattn_fwd")
+            check(_timed(f"masked_xattn_fwd_N{N}", q, lambda: lib.wm2f_masked_xattn_fwd(
+                _p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(ws), B, heads, Q, N, D, WM2F_F32,
+                _stream(q))), "wm2f_masked_xattn_fwd")
         ctx.save_for_backward(q, k, v, mask, row_open, out, lse)
         ctx.heads = heads
         return out
@@ -214,36 +252,44 @@ def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, 
 # ----------------------------------------------------------------------------------------- point sampling
 class _PointSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, pts):
+    def forward(ctx, feat, pts, map_index):
         tdt = 1 if feat.dtype in (torch.uint8, torch.bool) else 0
         if feat.dtype == torch.bool:
             feat = feat.view(torch.uint8)
         feat = _req(feat, "feat", torch.uint8 if tdt else torch.float32)
         pts = _req(pts, "pts")
         N, H, W = feat.shape
-        P = pts.shape[1]
-        if pts.shape != (N, P, 2):
-            raise ValueError(f"point_sample: feat {tuple(feat.shape)} pts {tuple(pts.shape)}")
-        out = torch.empty(N, P, device=feat.device, dtype=torch.float32)
+        M, P = pts.shape[:2]
+        if pts.dim() != 3 or pts.shape[2] != 2:
+            raise ValueError(f"point_sample: pts {tuple(pts.shape)}")
+        if map_index is None:
+            if M != N:
+                raise ValueError(f"point_sample: {M} point rows for {N} maps and no map_index")
+        else:
+            map_index = _req(map_index, "map_index", torch.int32)
+            if map_index.shape != (M,):
+                raise ValueError(f"point_sample: map_index {tuple(map_index.shape)} != ({M},)")
+        out = torch.empty(M, P, device=feat.device, dtype=torch.float32)
         with torch.cuda.device(feat.device):
-            check(load().wm2f_point_sample_fwd(_p(feat), tdt, _p(pts), _p(out), N, H, W, P, _stream(feat)),
-                  "wm2f_point_sample_fwd")
-        ctx.save_for_backward(pts)
+            check(load().wm2f_point_sample_fwd(_p(feat), tdt, _p(pts), _p(map_index), _p(out), M, H, W, P,
+                                               _stream(feat)), "wm2f_point_sample_fwd")
+        ctx.save_for_backward(pts, map_index)
         ctx.shape = (N, H, W)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (pts,) = ctx.saved_tensors
+        pts, map_index = ctx.saved_tensors
         N, H, W = ctx.shape
         grad_out = _req(grad_out, "grad_out")
         g = torch.zeros(N, H, W, device=pts.device, dtype=torch.float32)
         with torch.cuda.device(pts.device):
-            check(load().wm2f_point_sample_bwd(_p(grad_out), _p(pts), _p(g), N, H, W, pts.shape[1], _stream(pts)),
-                  "wm2f_point_sample_bwd")
-        return g, None
+            check(load().wm2f_point_sample_bwd(_p(grad_out), _p(pts), _p(map_index), _p(g), pts.shape[0], H, W,
+                                               pts.shape[1], _stream(pts)), "wm2f_point_sample_bwd")
+        return g, None, None
 
 
-def point_sample(feat: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
-    """sample_point (HF:245-274) for single-channel maps: feat (N,H,W), pts (N,P,2) in [0,1] (x,y) -> (N,P)."""
-    return _PointSample.apply(feat, pts)
+def point_sample(feat: torch.Tensor, pts: torch.Tensor, map_index: torch.Tensor | None = None) -> torch.Tensor:
+    """sample_point (HF:245-274) for single-channel maps: feat (N,H,W), pts (M,P,2) in [0,1] (x,y) -> (M,P).
+    Row m samples feat[map_index[m]] (int32) -- or feat[m] when map_index is None."""
+    return _PointSample.apply(feat, pts, map_index)
