@@ -65,7 +65,9 @@ def cpu_baseline(model, size, n_images, seed=0):
     cfg = model.config.to_dict()
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n_images, 3, size, size, generator=g)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box exposes every host core but a 1-GPU job owns a share of 16 (gpurun rules); more
+    # threads than that only oversubscribe (measured: 256 threads -> 16x slower)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     t0 = time.perf_counter()
     res = O.forward(sd, cfg, x)
     dt = time.perf_counter() - t0
