@@ -72,6 +72,19 @@ int wm2f_msdeform_fused_fwd(const void* value, const void* offsets, const void* 
                             void* out, const int32_t* level_hw, int B, int S, int Q, int heads, int D,
                             int L, int P, int dtype, void* stream);
 
+/* Same two operations with the kernel variant exposed (A/B measurement, tuning):
+ *   fused   0: a = loc, b = attn_w, ref unused      1: a = offsets, b = logits, ref as above
+ *   variant 0: auto   1: direct gather (any D)   2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4)
+ *           12 / 22 / 32 / 42 / 52: timing ablations of the LDS-window kernel (staging only, gather
+ *           only, no operand loads, no LDS reads, neither) -- their OUTPUTS ARE NOT VALID;
+ *           62: LDS-window kernel with slab-major work order
+ *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that
+ *           from their reference point take a slow path (results never depend on it).
+ * wm2f_msdeform_fwd / _fused_fwd are variant 0, margin 4. */
+int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const void* ref, void* out,
+                        const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
+                        int dtype, int fused, int variant, int margin, void* stream);
+
 /* ---- K3: mask einsum --------------------------------------------------------------------
  * Replaces torch.einsum("bqc,bchw->bqhw"), HF:2046.
  *   emb (B, Q, C)   pix (B, C, HW)   out (B, Q, HW)      C % 16 == 0

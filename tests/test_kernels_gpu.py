@@ -75,6 +75,45 @@ def test_k1_fused_prologue(ops):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("variant,margin", [(1, 4), (2, 4), (2, 0), (62, 1), (0, 7)])
+@pytest.mark.parametrize("tag", ["toy", "rect"])
+def test_k1_variants_golden(ops, tag, variant, margin):
+    """Direct-gather and LDS-window kernels give the same answer; the window margin never changes it
+    (the golden locations are spread far outside any margin, so the slow path is exercised)."""
+    g = load_golden(f"k1_msdeform_{tag}.npz")
+    out = ops.ms_deform_attn_variant(dev(T(g["value"])), g["level_hw"].tolist(), dev(T(g["loc"])), dev(T(g["w"])),
+                                     variant=variant, margin=margin)
+    torch.testing.assert_close(out.cpu(), T(g["out"]), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("shapes,B", [([(8, 8), (16, 16), (32, 32)], 2), ([(5, 7), (10, 14), (20, 28)], 3),
+                                      ([(7, 9), (13, 17), (25, 33)], 1), ([(12, 20), (24, 40)], 2),
+                                      ([(32, 32), (64, 64), (128, 128)], 1)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_k1_tiled_local_offsets(ops, shapes, B, fused):
+    """Offsets of a few pixels around the reference points (the module's regime): fast LDS path,
+    odd level sizes included (tiles with ragged query counts)."""
+    H, D, L, P = 8, 32, len(shapes), 4
+    g = torch.Generator().manual_seed(11)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * 2.5
+    off[0, 3, 0, 0, 0] = torch.tensor([40.0, -35.0])  # far outlier -> slow path
+    logits = torch.randn(B, S, H, L * P, generator=g)
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw = torch.softmax(logits, -1).view(B, S, H, L, P)
+    ref = O.msdeform_attn_core(value, shapes, loc, aw)
+    for margin, variant in ((4, 2), (2, 2), (4, 62)):
+        if fused:
+            out = ops.ms_deform_attn_variant(dev(value), shapes, dev(off), dev(logits), dev(ref_pts), fused=True,
+                                             variant=variant, margin=margin)
+        else:
+            out = ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(aw), variant=variant, margin=margin)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
 def test_k1_backward(ops):
     shapes = [(4, 6), (8, 12), (16, 24)]
     value, loc, w = _rand_k1(2, shapes, 8, 32, 3, spread=1.1)

@@ -39,12 +39,13 @@ def main():
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device="cpu").manual_seed(0)
     res = {}
-    if "k1" in only or "k1f" in only:
+    if "k1" in only or "k1f" in only or "k1v" in only or "k1t" in only:
         value = torch.randn(B, S, H, D, device=dev)
         # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
                          for h, w in shapes]).to(dev)  # (S,2) x,y
-        off = (torch.randn(B, S, H, L, P, 2, device=dev) * 2.0)
+        # the module's initial pattern: |offset| <= 4 px (HF:2154-2166); uniform in [-4, 4]
+        off = (torch.rand(B, S, H, L, P, 2, device=dev) * 8.0 - 4.0)
         norm = torch.tensor([[w, h] for h, w in shapes], device=dev, dtype=torch.float32)
         loc = (ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
         logits = torch.randn(B, S, H, L * P, device=dev)
@@ -54,8 +55,20 @@ def main():
             r = timeit(lambda: ops.ms_deform_attn(value, shapes, loc, aw), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
             res["k1_msdeform_fwd"] = r
+        refl = ref[:, None, :].expand(S, L, 2).contiguous()
+        if "k1v" in only:
+            for variant, margin in ((1, 4), (2, 4), (12, 4), (22, 4), (52, 4), (62, 4)):
+                r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, loc, aw, variant=variant, margin=margin), a.iters)
+                r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
+                res[f"k1_unfused_variant{variant}_margin{margin}"] = r
+                r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=variant, margin=margin), a.iters)
+                r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
+                res[f"k1_fused_variant{variant}_margin{margin}"] = r
+        if "k1t" in only:  # one variant only, for PMC runs
+            r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=2, margin=4), a.iters)
+            r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
+            res["k1_fused_variant2_margin4"] = r
         if "k1f" in only:
-            refl = ref[:, None, :].expand(S, L, 2).contiguous()
             r = timeit(lambda: ops.ms_deform_attn_fused(value, shapes, off, logits, refl), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
             res["k1_msdeform_fused_fwd"] = r

@@ -237,6 +237,12 @@ static int fill_levels(LevelInfo& lv, const int32_t* level_hw, int L, int S, con
   return WM2F_OK;
 }
 
+// msdeform_tiled.hip
+template <bool FUSED>
+int launch_tiled(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
+                 int Q, int heads, int L, int P, int margin, int threads, void* stream, const char* who,
+                 bool* handled, int mode);
+
 struct LaunchGeom {
   int64_t n_pairs;
   int n_blocks, blocks_per_xcd, grid;
@@ -253,16 +259,31 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
   return g;
 }
 
+// variant: 0 = auto (LDS-window kernel when it applies, else direct gather), 1 = direct,
+//          2 = LDS-window kernel only; 12/22/32/42/52/62 = its timing ablations (invalid outputs
+//          except 62 = slab-major work order)
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
-                      void* stream, const char* who) {
+                      void* stream, const char* who, int variant = 0, int margin = 4) {
   WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
   WM2F_REQUIRE(value && a && b && out && level_hw && (!FUSED || ref), "%s: null pointer", who);
   WM2F_REQUIRE(B > 0 && S > 0 && Q > 0 && heads > 0 && P > 0, "%s: non-positive size", who);
   WM2F_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {8,16,32,64}", who, D);
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  if (variant != 1 && D == 32) {
+    bool handled = false;
+    if (int rc = launch_tiled<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, margin,
+                                     512, stream, who, &handled,
+                                     variant >= 12 && variant % 10 == 2 ? variant / 10 : 0))
+      return rc;
+    if (handled) return WM2F_OK;
+  }
+  if (variant >= 2) {
+    set_error("%s: the LDS-window kernel does not apply to this shape (needs D=32, P=4, Q==S, L<=4)", who);
+    return WM2F_EUNSUPPORTED;
+  }
   const LaunchGeom g = geom(B, Q, heads, D);
   hipStream_t st = (hipStream_t)stream;
 #define WM2F_LAUNCH_FWD(DD, PC)                                                                       \
@@ -299,6 +320,16 @@ extern "C" int wm2f_msdeform_fused_fwd(const void* value, const void* offsets, c
                                        int L, int P, int dtype, void* stream) {
   return launch_fwd<true>(value, offsets, logits, ref, out, level_hw, B, S, Q, heads, D, L, P, dtype, stream,
                           "wm2f_msdeform_fused_fwd");
+}
+
+extern "C" int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const void* ref, void* out,
+                                   const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
+                                   int dtype, int fused, int variant, int margin, void* stream) {
+  if (fused)
+    return launch_fwd<true>(value, a, b, ref, out, level_hw, B, S, Q, heads, D, L, P, dtype, stream,
+                            "wm2f_msdeform_fwd_v", variant, margin);
+  return launch_fwd<false>(value, a, b, nullptr, out, level_hw, B, S, Q, heads, D, L, P, dtype, stream,
+                           "wm2f_msdeform_fwd_v", variant, margin);
 }
 
 extern "C" int wm2f_msdeform_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out,

@@ -132,6 +132,23 @@ def ms_deform_attn_fused(value: torch.Tensor, level_hw, offsets: torch.Tensor, l
     return out
 
 
+def ms_deform_attn_variant(value, level_hw, a, b, ref=None, fused=False, variant=0, margin=4) -> torch.Tensor:
+    """K1 with the kernel variant exposed (no autograd): variant 0 auto, 1 direct gather, 2 LDS windows.
+    fused=False: a = loc, b = attn_w.  fused=True: a = raw offsets, b = raw logits, ref (Q,L,2)."""
+    value, a, b = _req(value, "value"), _req(a, "a"), _req(b, "b")
+    if fused:
+        ref = _req(ref, "ref")
+    B, S, H, D = value.shape
+    _, Q, _, L, P, _ = a.shape
+    out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
+    lv = host_i32([x for hw in level_hw for x in hw])
+    with torch.cuda.device(value.device):
+        check(_timed(f"msdeform_v{variant}", value, lambda: load().wm2f_msdeform_fwd_v(
+            _p(value), _p(a), _p(b), _p(ref if fused else None), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32,
+            1 if fused else 0, int(variant), int(margin), _stream(value))), "wm2f_msdeform_fwd_v")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- K3
 class _MaskEinsum(torch.autograd.Function):
     @staticmethod
