@@ -117,6 +117,16 @@ int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v, const voi
                           const void* row_open, void* out, void* lse, void* workspace,
                           int B, int heads, int Q, int N, int D, int dtype, void* stream);
 
+/* Backward of the above (P is recomputed from q, k and lse).  grad_q is the gradient w.r.t. the
+ * PRE-SCALED q; grad_q / grad_k / grad_v are overwritten.
+ *   out, lse: the forward's results; grad_out (B, Q, heads*D)
+ *   workspace: at least wm2f_masked_xattn_bwd_workspace(...) bytes */
+int64_t wm2f_masked_xattn_bwd_workspace(int B, int heads, int Q, int N, int D);
+int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v, const void* mask,
+                          const void* row_open, const void* out, const void* lse, const void* grad_out,
+                          void* grad_q, void* grad_k, void* grad_v, void* workspace,
+                          int B, int heads, int Q, int N, int D, int dtype, void* stream);
+
 /* ---- K4: Hungarian-matcher cost matrices ------------------------------------------------------
  * Replaces Mask2FormerHungarianMatcher.forward up to (not including) the scipy solver,
  * HF:444-472 with sample_point HF:245-274 and the pair-wise losses HF:328-374, batched over

@@ -429,14 +429,15 @@ def transformer_module(sd, prefix, multi_scale, mask_features, cfg):
     return inter, all_masks
 
 
-def forward(sd, cfg, pixel_values, mask_labels=None, class_labels=None, rand_source=None, backbone_feats=None):
+def forward(sd, cfg, pixel_values, mask_labels=None, class_labels=None, rand_source=None, backbone_feats=None,
+            grad=False):
     """Mask2FormerForUniversalSegmentation.forward, HF:2332-2530, eval mode.
 
     sd: state dict with the dependency's names.  cfg: its config as a dict.
     Returns dict(masks_queries_logits, class_queries_logits, aux_masks, aux_classes, loss, loss_dict, indices,
     mask_features, multi_scale, backbone)."""
-    sd = {k: v.float() if v.is_floating_point() else v for k, v in sd.items()}
-    with torch.no_grad():
+    sd = {k: v.float() if (v.is_floating_point() and v.dtype != torch.float32) else v for k, v in sd.items()}
+    with torch.enable_grad() if grad else torch.no_grad():
         rs = rand_source or RandSource()
         for _ in range(cfg["decoder_layers"] - 1):
             pass  # the dependency draws rand([]) per decoder layer (HF:1905); replay lists strip them beforehand

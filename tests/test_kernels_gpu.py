@@ -210,6 +210,33 @@ def test_k2_random(ops, B, H, Q, N, D, use_mask):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,Q,N,D,use_mask", [(2, 8, 100, 256, 32, True), (1, 2, 10, 37, 32, True),
+                                                (1, 4, 50, 130, 32, False), (1, 2, 30, 100, 64, True),
+                                                (1, 4, 20, 70, 16, True)])
+def test_k2_backward(ops, B, H, Q, N, D, use_mask):
+    g = torch.Generator().manual_seed(17)
+    E = H * D
+    q = torch.randn(B, Q, E, generator=g) * 0.5
+    k = torch.randn(B, N, E, generator=g)
+    v = torch.randn(B, N, E, generator=g)
+    go = torch.randn(B, Q, E, generator=g)
+    mask = torch.rand(B, Q, N, generator=g) < 0.6
+    mask[0, 0] = True
+    if not use_mask:
+        mask = torch.zeros_like(mask)
+    sh = lambda t, n: t.view(B, n, H, D).permute(0, 2, 1, 3)
+    q0, k0, v0 = q.clone().requires_grad_(), k.clone().requires_grad_(), v.clone().requires_grad_()
+    ref = O.masked_attention_core(sh(q0, Q), sh(k0, N), sh(v0, N), mask).permute(0, 2, 1, 3).reshape(B, Q, E)
+    ref.backward(go)
+    q1, k1, v1 = dev(q).requires_grad_(), dev(k).requires_grad_(), dev(v).requires_grad_()
+    ro = (~mask.all(-1)).to(torch.int32)
+    out = ops.masked_xattn(q1, k1, v1, dev(mask.to(torch.uint8)) if use_mask else None, dev(ro) if use_mask else None, H)
+    out.backward(dev(go))
+    torch.testing.assert_close(q1.grad.cpu(), q0.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(k1.grad.cpu(), k0.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(v1.grad.cpu(), v0.grad, rtol=1e-4, atol=2e-5)
+
+
 # ----------------------------------------------------------------------------------------- K4
 def test_k4_golden_cost_and_indices(ops):
     g = load_golden("k4_matcher.npz")

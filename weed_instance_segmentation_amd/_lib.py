@@ -30,6 +30,8 @@ SIGNATURES = {
     "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_masked_xattn_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_masked_xattn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_masked_xattn_bwd_workspace": (c_int64, [_I, _I, _I, _I, _I]),
+    "wm2f_masked_xattn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_matcher_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_matcher_cost": (c_int, [_P, _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                   c_float, c_float, c_float, _P]),

@@ -318,3 +318,263 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
+
+// =====================================================================================================
+// Backward.  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - delta), delta[q] = sum_d dO[q][d] O[q][d];
+// dQ = dS K;  dK = dS^T Q.   P is recomputed from q, k and the forward's log-sum-exp.
+//
+// Orientation (the opposite of the forward): S and dP are computed with the KEY on the lane column
+// (S = Q K^T, C layout: column = key, rows = queries 4g+r), so that P and dS are directly the B operands
+// of   dV^T[d][key] += dO^T[d][q] P[q][key]   and   dK^T[d][key] += Q^T[d][q] dS[q][key],
+// whose accumulators (column = key, rows = d) store straight into dV / dK rows as float4.  Only dQ needs
+// dS with the query on the lane: one 16x16 tile per step crosses a wave-private LDS tile.
+// A wave owns whole 16-key tiles -> dK, dV need no reduction; dQ partials are merged over the 4 waves
+// through LDS, over the key splits by a small second kernel.
+namespace wm2f {
+
+template <int D>
+__global__ __launch_bounds__(256) void xattn_delta_kernel(const float* __restrict__ out, const float* __restrict__ go,
+                                                          float* __restrict__ delta, int B, int heads, int Q) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, q)
+  if (idx >= (int64_t)B * heads * Q) return;
+  const int qi = (int)(idx % Q);
+  const int64_t bh = idx / Q;
+  const int h = (int)(bh % heads), b = (int)(bh / heads);
+  const float* o = out + ((int64_t)b * Q + qi) * heads * D + h * D;
+  const float* g = go + ((int64_t)b * Q + qi) * heads * D + h * D;
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; d += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(o + d), c = *reinterpret_cast<const float4*>(g + d);
+    s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+  }
+  delta[idx] = s;
+}
+
+template <int NQT, int D>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ go, float* __restrict__ dq_ws,
+    float* __restrict__ dk, float* __restrict__ dv, int Q, int N, int heads, int n_splits, int tiles_per_split) {
+  constexpr int DK = D / 4;   // k-steps of S / dP: lane group g owns d = DK*g .. DK*g+DK-1
+  constexpr int DT = D / 16;  // 16-wide d tiles
+  constexpr int QL = NQT * 16;
+  constexpr int TS = 20;  // padded row of the dS transpose tile (keeps float4 alignment)
+  __shared__ __attribute__((aligned(16))) float tr[kXWaves][16][TS];
+  __shared__ __attribute__((aligned(16))) float dq_part[kXWaves][QL][D];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x % n_splits, qc = blockIdx.x / n_splits;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qc * QL;
+  const int E = heads * D;
+  const float* qb = q + (int64_t)b * Q * E + h * D;
+  const float* gob = go + (int64_t)b * Q * E + h * D;
+  const float* kb = k + (int64_t)b * N * E + h * D;
+  const float* vb = v + (int64_t)b * N * E + h * D;
+  const float* lseb = lse + ((int64_t)b * heads + h) * Q;
+  const float* delb = delta + ((int64_t)b * heads + h) * Q;
+
+  f32x4 dqa[NQT][DT];
+#pragma unroll
+  for (int jq = 0; jq < NQT; ++jq)
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dqa[jq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int n_tiles = ceil_div(N, 16);
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+
+  for (int tile = split * tiles_per_split + wave; tile < t_end; tile += kXWaves) {
+    const int key0 = tile * 16;
+    int kk = key0 + n;
+    const bool key_ok = kk < N;
+    if (!key_ok) kk = N - 1;
+    // B operands of S and dP: lane (key = key0+n, d = DK*g + t)
+    float kf[DK], vf[DK];
+#pragma unroll
+    for (int t = 0; t < DK; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(kb + (int64_t)kk * E + DK * g + t);
+      const float4 y = *reinterpret_cast<const float4*>(vb + (int64_t)kk * E + DK * g + t);
+      kf[t] = x.x; kf[t + 1] = x.y; kf[t + 2] = x.z; kf[t + 3] = x.w;
+      vf[t] = y.x; vf[t + 1] = y.y; vf[t + 2] = y.z; vf[t + 3] = y.w;
+    }
+    // B operand of dQ: lane (key = key0 + 4g + t, d = 16i + n)
+    float kr[DT][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int k2 = key0 + 4 * g + t;
+      if (k2 > N - 1) k2 = N - 1;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) kr[i][t] = kb[(int64_t)k2 * E + 16 * i + n];
+    }
+    f32x4 dvt[DT], dkt[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dvt[i] = dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int jq = 0; jq < NQT; ++jq) {
+      // A operands of S and dP: lane (q = 16jq + n, d = DK*g + t)
+      int qa = q0 + 16 * jq + n;
+      if (qa > Q - 1) qa = Q - 1;
+      float qf[DK], gf[DK];
+#pragma unroll
+      for (int t = 0; t < DK; t += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(qb + (int64_t)qa * E + DK * g + t);
+        const float4 y = *reinterpret_cast<const float4*>(gob + (int64_t)qa * E + DK * g + t);
+        qf[t] = x.x; qf[t + 1] = x.y; qf[t + 2] = x.z; qf[t + 3] = x.w;
+        gf[t] = y.x; gf[t + 1] = y.y; gf[t + 2] = y.z; gf[t + 3] = y.w;
+      }
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < DK; ++t) {
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[t], kf[t], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[t], vf[t], dp, 0, 0, 0);
+      }
+      // rows of this lane: q = q0 + 16jq + 4g + r
+      f32x4 p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + 16 * jq + 4 * g + r;
+        const bool q_ok = qi < Q;
+        const int qc2 = q_ok ? qi : Q - 1;
+        bool dead = !q_ok || !key_ok;
+        if (mask != nullptr && (row_open == nullptr || row_open[(int64_t)b * Q + qc2] != 0))
+          dead = dead || (mask[((int64_t)b * Q + qc2) * N + kk] != 0);
+        const float pv = dead ? 0.f : __expf(s[r] - lseb[qc2]);
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - delb[qc2]);
+      }
+      // A operands of dV^T / dK^T: lane (d = 16i + n, q = 16jq + 4g + t)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int q2 = q0 + 16 * jq + 4 * g + t;
+        if (q2 > Q - 1) q2 = Q - 1;  // p, ds are zero there
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+          const float got = gob[(int64_t)q2 * E + 16 * i + n];
+          const float qt = qb[(int64_t)q2 * E + 16 * i + n];
+          dvt[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(got, p[t], dvt[i], 0, 0, 0);
+          dkt[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt, ds[t], dkt[i], 0, 0, 0);
+        }
+      }
+      // dS to the query-on-lane layout through the wave's LDS tile, then dQ += dS K
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tr[wave][4 * g + r][n] = ds[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float4 dst4 = *reinterpret_cast<const float4*>(&tr[wave][n][4 * g]);  // lane (q = n, keys 4g..4g+3)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float dsa[4] = {dst4.x, dst4.y, dst4.z, dst4.w};
+      // jq is wave-uniform but a runtime value: select the accumulator with static indices so that
+      // dqa stays in registers (a runtime-indexed vector array would go to scratch)
+#pragma unroll
+      for (int J = 0; J < NQT; ++J)
+        if (jq == J) {
+#pragma unroll
+          for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              dqa[J][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsa[t], kr[i][t], dqa[J][i], 0, 0, 0);
+        }
+    }
+    // dV^T / dK^T tiles: column = key n, rows d = 16i + 4g + r  ->  float4 along d
+    if (key_ok) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        *reinterpret_cast<f32x4*>(dv + ((int64_t)b * N + kk) * E + h * D + 16 * i + 4 * g) = dvt[i];
+        *reinterpret_cast<f32x4*>(dk + ((int64_t)b * N + kk) * E + h * D + 16 * i + 4 * g) = dkt[i];
+      }
+    }
+  }
+
+  // ---- merge dQ over the 4 waves: C layout of dqa is (column = d n, rows q = 4g + r)
+#pragma unroll
+  for (int jq = 0; jq < NQT; ++jq)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq_part[wave][16 * jq + 4 * g + r][16 * i + n] = dqa[jq][i][r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < QL * (D / 4); idx += kXWaves * kWave) {
+    const int ql = idx / (D / 4), c = idx - ql * (D / 4);
+    const int qi = q0 + ql;
+    if (qi >= Q) continue;
+    float4 a = *reinterpret_cast<const float4*>(&dq_part[0][ql][4 * c]);
+#pragma unroll
+    for (int w = 1; w < kXWaves; ++w) {
+      const float4 x = *reinterpret_cast<const float4*>(&dq_part[w][ql][4 * c]);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+    *reinterpret_cast<float4*>(dq_ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * D + 4 * c) = a;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void xattn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq,
+                                                              int B, int heads, int Q, int n_splits) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, h, q, float4 chunk)
+  constexpr int CH = D / 4;
+  if (idx >= (int64_t)B * heads * Q * CH) return;
+  const int c = (int)(idx % CH);
+  const int64_t row = idx / CH;
+  const int qi = (int)(row % Q);
+  const int64_t bh = row / Q;
+  const int h = (int)(bh % heads), b = (int)(bh / heads);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < n_splits; ++s) {
+    const float4 x = *reinterpret_cast<const float4*>(ws + (row * n_splits + s) * D + 4 * c);
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+  }
+  *reinterpret_cast<float4*>(dq + ((int64_t)b * Q + qi) * heads * D + h * D + 4 * c) = a;
+}
+
+}  // namespace wm2f
+
+extern "C" int64_t wm2f_masked_xattn_bwd_workspace(int B, int heads, int Q, int N, int D) {
+  if (B <= 0 || heads <= 0 || Q <= 0 || N <= 0 || D <= 0) return 0;
+  // dQ partials per split + delta
+  return ((int64_t)B * heads * Q * xattn_splits(B, heads, N) * D + (int64_t)B * heads * Q) * 4;
+}
+
+extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v, const void* mask,
+                                     const void* row_open, const void* out, const void* lse, const void* grad_out,
+                                     void* grad_q, void* grad_k, void* grad_v, void* workspace, int B, int heads,
+                                     int Q, int N, int D, int dtype, void* stream) {
+  const char* who = "wm2f_masked_xattn_bwd";
+  WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
+  WM2F_REQUIRE(q && k && v && out && lse && grad_out && grad_q && grad_k && grad_v && workspace, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && heads > 0 && Q > 0 && N > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {16,32,64}", who, D);
+  WM2F_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads / B exceed the grid limits", who);
+  const int n_splits = xattn_splits(B, heads, N);
+  const int tps = ceil_div(ceil_div(N, 16), n_splits);
+  hipStream_t st = (hipStream_t)stream;
+  float* dq_ws = (float*)workspace;
+  float* delta = dq_ws + (int64_t)B * heads * Q * n_splits * D;
+  const int64_t nrow = (int64_t)B * heads * Q;
+#define WM2F_BD(Dv, NQTv)                                                                                          \
+  {                                                                                                                \
+    hipLaunchKernelGGL((xattn_delta_kernel<Dv>), dim3((unsigned)ceil_div64(nrow, 256)), dim3(256), 0, st,          \
+                       (const float*)out, (const float*)grad_out, delta, B, heads, Q);                             \
+    dim3 grid(n_splits* ceil_div(Q, NQTv * 16), heads, B);                                                         \
+    hipLaunchKernelGGL((masked_xattn_bwd_kernel<NQTv, Dv>), grid, dim3(kXWaves* kWave), 0, st, (const float*)q,    \
+                       (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,               \
+                       (const float*)lse, (const float*)delta, (const float*)grad_out, dq_ws, (float*)grad_k,      \
+                       (float*)grad_v, Q, N, heads, n_splits, tps);                                                \
+    hipLaunchKernelGGL((xattn_dq_reduce_kernel<Dv>), dim3((unsigned)ceil_div64(nrow*(Dv / 4), 256)), dim3(256), 0, \
+                       st, (const float*)dq_ws, (float*)grad_q, B, heads, Q, n_splits);                            \
+  }
+  const int q_tiles = ceil_div(Q, 16);
+  if (D == 16) {
+    if (q_tiles <= 4) WM2F_BD(16, 4) else WM2F_BD(16, 7)
+  } else if (D == 32) {
+    if (q_tiles <= 4) WM2F_BD(32, 4) else WM2F_BD(32, 7)
+  } else {
+    WM2F_BD(64, 3)
+  }
+#undef WM2F_BD
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

@@ -224,7 +224,19 @@ class _MaskedXAttn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError("masked_xattn backward (wm2f_masked_xattn_bwd) is not built yet")
+        q, k, v, mask, row_open, out, lse = ctx.saved_tensors
+        grad_out = _req(grad_out, "grad_out")
+        B, Q, E = q.shape
+        N, heads = k.shape[1], ctx.heads
+        D = E // heads
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        lib = load()
+        ws = torch.empty(int(lib.wm2f_masked_xattn_bwd_workspace(B, heads, Q, N, D)), device=q.device, dtype=torch.uint8)
+        with torch.cuda.device(q.device):
+            check(_timed(f"masked_xattn_bwd_N{N}", q, lambda: lib.wm2f_masked_xattn_bwd(
+                _p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(grad_out), _p(gq), _p(gk), _p(gv),
+                _p(ws), B, heads, Q, N, D, WM2F_F32, _stream(q))), "wm2f_masked_xattn_bwd")
+        return gq, gk, gv, None, None, None
 
 
 def masked_xattn(q, k, v, mask, row_open, heads: int) -> torch.Tensor:
