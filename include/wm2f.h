@@ -72,6 +72,13 @@ int wm2f_msdeform_fused_fwd(const void* value, const void* offsets, const void* 
                             void* out, const int32_t* level_hw, int B, int S, int Q, int heads, int D,
                             int L, int P, int dtype, void* stream);
 
+/* Fused variant reading the two projections from ONE packed row per token, as a single merged
+ * Linear writes them:  packed (B, Q, heads*L*P*3) = [offsets (heads,L,P,2) | logits (heads,L*P)].
+ * LDS-window kernel only (D = 32, P = 4, Q == S, L <= 4); returns WM2F_EUNSUPPORTED otherwise. */
+int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* out,
+                                   const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L,
+                                   int P, int dtype, int margin, void* stream);
+
 /* Same two operations with the kernel variant exposed (A/B measurement, tuning):
  *   fused   0: a = loc, b = attn_w, ref unused      1: a = offsets, b = logits, ref as above
  *   variant 0: auto   1: direct gather (any D)   2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4)
@@ -157,6 +164,18 @@ int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, con
                           void* out, int M, int H, int W, int P, void* stream);
 int wm2f_point_sample_bwd(const void* grad_out, const void* pts, const void* map_index, void* grad_feat,
                           int M, int H, int W, int P, void* stream);
+
+/* ---- fused HBM-bound passes around the stock GEMMs / convolutions (inference) -------------------
+ * wm2f_bias_act:      y = act(x + bias[c] (+ residual)), x / y / residual (N, C, H*W) fp32, H*W % 4 == 0;
+ *                     y may alias x.  relu = 1 applies max(., 0).
+ * wm2f_add_layernorm: out = LayerNorm(x + residual) * gamma + beta over rows of C = 256 (HF:1076-1078,
+ *                     :1086-1088); residual may be NULL; if out_plus_pos != NULL it receives
+ *                     out + pos[row % pos_rows] (the next layer's `hidden + pos`, HF:972). */
+int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y, int N, int C, int HW,
+                  int relu, void* stream);
+int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,
+                       const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
+                       int64_t pos_rows, float eps, void* stream);
 
 #ifdef __cplusplus
 }

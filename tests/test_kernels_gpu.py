@@ -114,6 +114,25 @@ def test_k1_tiled_local_offsets(ops, shapes, B, fused):
         torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shapes,D", [([(8, 8), (16, 16), (32, 32)], 32), ([(5, 7), (10, 14), (20, 28)], 32),
+                                      ([(4, 4), (8, 8), (16, 16)], 16)])
+def test_k1_fused_packed(ops, shapes, D):
+    """One merged [offsets | logits] row per token (the module's inference path), incl. the fallback (D=16)."""
+    B, H, L, P = 2, 8, 3, 4
+    g = torch.Generator().manual_seed(12)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    packed = torch.randn(B, S, H * L * P * 3, generator=g) * 2
+    off = packed[..., :H * L * P * 2].reshape(B, S, H, L, P, 2)
+    logits = packed[..., H * L * P * 2:].reshape(B, S, H, L * P)
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    ref = O.msdeform_attn_core(value, shapes, loc, torch.softmax(logits, -1).view(B, S, H, L, P))
+    out = ops.ms_deform_attn_fused_packed(dev(value), shapes, dev(packed), dev(ref_pts), H, L, P)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
 def test_k1_backward(ops):
     shapes = [(4, 6), (8, 12), (16, 24)]
     value, loc, w = _rand_k1(2, shapes, 8, 32, 3, spread=1.1)
@@ -294,6 +313,26 @@ def test_point_sample_fwd_bwd(ops):
     u8 = (feat > 0).to(torch.uint8)
     out8 = ops.point_sample(dev(u8), dev(pts)).cpu()
     torch.testing.assert_close(out8, O.sample_point(u8[:, None].float(), pts)[:, 0], rtol=1e-5, atol=1e-6)
+
+
+def test_fused_elementwise(ops):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 16, 6, 10, generator=g)
+    bias, res = torch.randn(16, generator=g), torch.randn(3, 16, 6, 10, generator=g)
+    for r, relu in ((None, True), (res, True), (res, False), (None, False)):
+        ref = x + bias[None, :, None, None] + (0 if r is None else r)
+        ref = torch.relu(ref) if relu else ref
+        out = ops.bias_act_(dev(x.clone()), dev(bias), None if r is None else dev(r), relu)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    rows, C = 77, 256
+    a, b = torch.randn(2, rows, C, generator=g) * 3, torch.randn(2, rows, C, generator=g)
+    gamma, beta, pos = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(rows, C, generator=g)
+    ref = torch.nn.functional.layer_norm(a + b, (C,), gamma, beta, 1e-5)
+    out, outp = ops.add_layernorm(dev(a), dev(b), dev(gamma), dev(beta), 1e-5, pos=dev(pos))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outp.cpu(), ref + pos[None], rtol=1e-5, atol=1e-5)
+    out2 = ops.add_layernorm(dev(a), None, dev(gamma), dev(beta), 1e-5)
+    torch.testing.assert_close(out2.cpu(), torch.nn.functional.layer_norm(a, (C,), gamma, beta, 1e-5), rtol=1e-5, atol=1e-5)
 
 
 def test_cpu_tensor_is_refused(ops):

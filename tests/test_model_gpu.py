@@ -132,3 +132,37 @@ def test_parameter_gradients_match_oracle(tiny):
         scale = b.abs().max().item() + 1e-12
         err = (a - b).abs().max().item() / scale
         assert err < 2e-3, f"{n}: rel err {err:.3e}"
+
+
+def test_forward_dim256_fused_inference_paths():
+    """feature_size 256 / 8 heads (head_dim 32): the module takes the LDS-window K1 with the merged
+    projection, the fused residual+LayerNorm, the folded-BatchNorm epilogues -- checked against the oracle
+    on the same (random) weights, under no_grad (fused paths) AND with grad enabled (plain paths)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    bc = dict(model_type="resnet", num_channels=3, embedding_size=16, hidden_sizes=[32, 64, 128, 256], depths=[1, 2, 1, 1],
+              layer_type="bottleneck", out_features=["stage1", "stage2", "stage3", "stage4"])
+    cfg = Mask2FormerConfig(backbone_config=bc, num_labels=3, num_queries=20, encoder_layers=2, decoder_layers=4,
+                            dim_feedforward=128, encoder_feedforward_dim=256)
+    torch.manual_seed(3)
+    m = Mask2FormerForUniversalSegmentation(cfg)
+    with torch.no_grad():  # make every parameter and statistic count
+        g = torch.Generator().manual_seed(4)
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.03)
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.add_(torch.randn(b.shape, generator=g) * 0.1)
+            elif n.endswith("running_var"):
+                b.mul_(1 + 0.3 * torch.rand(b.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(5))
+    ref = O.forward(sd, cfg.to_dict(), x)["masks_queries_logits"]
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out_ng = m(pixel_values=x.cuda()).masks_queries_logits.cpu()
+    out_g = m(pixel_values=x.cuda()).masks_queries_logits.detach().cpu()
+    for out in (out_ng, out_g):
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-3, err

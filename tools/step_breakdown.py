@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-kernel totals of the LAST forward step in a rocprofv3 kernel trace of bench.py (fwd mode).
+usage: step_breakdown.py <kernel_trace.csv> [top_n]"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [r for r in rows if "attn_mask_build" in r["Kernel_Name"]]  # 10 per forward, the last closes a step
+t0, t1 = int(marks[-11]["End_Timestamp"]), int(marks[-1]["End_Timestamp"])
+sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1]
+agg = collections.defaultdict(lambda: [0, 0])
+for r in sel:
+    agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg[r["Kernel_Name"]][1] += 1
+tot = sum(v[0] for v in agg.values())
+print(f"last step: wall {(t1 - t0) / 1e6:.2f} ms, kernel sum {tot / 1e6:.2f} ms, {len(sel)} launches")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+    print(f"{k[:100]:100s} n={v[1]:4d} ms={v[0] / 1e6:7.3f} avg_us={v[0] / v[1] / 1e3:8.1f}")

@@ -25,6 +25,7 @@ SIGNATURES = {
     "wm2f_msdeform_fwd": (c_int, [_P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_mask_einsum_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -35,6 +36,8 @@ SIGNATURES = {
     "wm2f_matcher_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_matcher_cost": (c_int, [_P, _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                   c_float, c_float, c_float, _P]),
+    "wm2f_bias_act": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "wm2f_add_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _I, c_int64, c_float, _P]),
     "wm2f_point_sample_fwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }

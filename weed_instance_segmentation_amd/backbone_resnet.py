@@ -11,6 +11,27 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import ops
+
+
+def _fused_ok(x: torch.Tensor) -> bool:
+    """Inference on the GPU with a float4-friendly map: use the fused bias(+residual)+ReLU pass."""
+    return (not torch.is_grad_enabled()) and x.dtype == torch.float32 and (x.shape[-1] * x.shape[-2]) % 4 == 0
+
+
+def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d, cache: dict):
+    """Inference-time BatchNorm folding: conv(x, w) * g/sqrt(v+eps) + (b - m*g/sqrt(v+eps)) == conv(x, w', b').
+    Cached per (weight / statistics version), so the fold is recomputed only after the parameters change."""
+    key = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+           bn.running_var._version, conv.weight.device, conv.weight.dtype)
+    if cache.get("key") != key:
+        with torch.no_grad():
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            cache["w"] = (conv.weight * scale[:, None, None, None]).contiguous()
+            cache["b"] = (bn.bias - bn.running_mean * scale).contiguous()
+            cache["key"] = key
+    return cache["w"], cache["b"]
+
 
 class ConvLayer(nn.Module):
     def __init__(self, cin, cout, kernel_size=3, stride=1, activation=True):
@@ -18,9 +39,32 @@ class ConvLayer(nn.Module):
         self.convolution = nn.Conv2d(cin, cout, kernel_size, stride, kernel_size // 2, bias=False)
         self.normalization = nn.BatchNorm2d(cout)
         self.activation = nn.ReLU() if activation else nn.Identity()
+        self._fold: dict = {}
 
-    def forward(self, x):
-        return self.activation(self.normalization(self.convolution(x)))
+    def forward(self, x, residual=None, extra_bias=None, force_relu=False):
+        """`residual` / `extra_bias` / `force_relu` let a bottleneck fold its shortcut add and final ReLU
+        into this layer's epilogue (inference only)."""
+        c = self.convolution
+        relu = force_relu or isinstance(self.activation, nn.ReLU)
+        if not self.training and not torch.is_grad_enabled():
+            # inference: convolution with folded BatchNorm statistics; bias (+ residual) + ReLU in ONE pass
+            w, b = _folded(c, self.normalization, self._fold)
+            if extra_bias is not None:
+                b = b + extra_bias
+            if _fused_ok(x):
+                y = torch.nn.functional.conv2d(x, w, None, c.stride, c.padding)
+                if (y.shape[-1] * y.shape[-2]) % 4 == 0:
+                    return ops.bias_act_(y, b, residual, relu)
+                y = y + b[None, :, None, None]
+            else:
+                y = torch.nn.functional.conv2d(x, w, b, c.stride, c.padding)
+            if residual is not None:
+                y = y + residual
+            return torch.relu(y) if relu else y
+        y = self.normalization(c(x))
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
 
 
 class ShortCut(nn.Module):
@@ -28,9 +72,16 @@ class ShortCut(nn.Module):
         super().__init__()
         self.convolution = nn.Conv2d(cin, cout, 1, stride, bias=False)
         self.normalization = nn.BatchNorm2d(cout)
+        self._fold: dict = {}
 
     def forward(self, x):
         return self.normalization(self.convolution(x))
+
+    def folded_raw(self, x):
+        """Inference: the shortcut convolution WITHOUT its folded bias, and that bias (the bottleneck adds it
+        in its fused epilogue)."""
+        w, b = _folded(self.convolution, self.normalization, self._fold)
+        return torch.nn.functional.conv2d(x, w, None, self.convolution.stride), b
 
 
 class BottleNeckLayer(nn.Module):
@@ -46,6 +97,12 @@ class BottleNeckLayer(nn.Module):
         self.activation = nn.ReLU()
 
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            h = self.layer[1](self.layer[0](x))
+            if isinstance(self.shortcut, ShortCut):
+                sc, sc_bias = self.shortcut.folded_raw(x)
+                return self.layer[2](h, residual=sc, extra_bias=sc_bias, force_relu=True)
+            return self.layer[2](h, residual=x, force_relu=True)
         return self.activation(self.layer(x) + self.shortcut(x))
 
 

@@ -1,0 +1,102 @@
+// Fused HBM-bound passes around the stock GEMMs / convolutions.
+//
+//  bias_act:       y = act(x + bias[c] (+ residual))       NCHW, in place or out of place
+//                  replaces the separate bias-add, residual-add and ReLU passes after a convolution whose
+//                  BatchNorm has been folded into its weights (inference).
+//  add_layernorm:  h = LayerNorm(x + res) * gamma + beta;  optionally also h + pos
+//                  replaces residual add + nn.LayerNorm (+ the next layer's `hidden + pos`),
+//                  transformers modeling_mask2former.py:1076-1078, :1086-1088.
+//                  One wave per row; C must be 256 (64 lanes x float4): two-pass mean / variance in
+//                  registers, exactly torch's formula (biased variance, eps inside the sqrt).
+// Both move each byte once: read x (+res) and write y -> bound by HBM.
+#include "common.h"
+
+namespace wm2f {
+
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, float* __restrict__ y,
+                                                       int64_t n4, int C, int HW4, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW4) % C);
+    const float b = bias[c];
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    if (res != nullptr) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void add_layernorm256_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ res,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ pos, float* __restrict__ out,
+                                                               float* __restrict__ out_pos, int64_t rows,
+                                                               int64_t pos_rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v = reinterpret_cast<const float4*>(x + row * 256)[lane];
+  if (res != nullptr) {
+    const float4 r = reinterpret_cast<const float4*>(res + row * 256)[lane];
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  const float mean = wave_sum64(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+  const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  const float var = wave_sum64(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+  const float rstd = rsqrtf(var + eps);
+  const float4 g = reinterpret_cast<const float4*>(gamma)[lane], b = reinterpret_cast<const float4*>(beta)[lane];
+  float4 o = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+  reinterpret_cast<float4*>(out + row * 256)[lane] = o;
+  if (out_pos != nullptr) {
+    const float4 p = reinterpret_cast<const float4*>(pos + (row % pos_rows) * 256)[lane];
+    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    reinterpret_cast<float4*>(out_pos + row * 256)[lane] = o;
+  }
+}
+
+}  // namespace wm2f
+
+using namespace wm2f;
+
+extern "C" int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y, int N, int C, int HW,
+                             int relu, void* stream) {
+  const char* who = "wm2f_bias_act";
+  WM2F_REQUIRE(x && bias && y, "%s: null pointer", who);
+  WM2F_REQUIRE(N > 0 && C > 0 && HW > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(HW % 4 == 0, "%s: H*W=%d must be a multiple of 4", who, HW);
+  const int64_t n4 = (int64_t)N * C * (HW / 4);
+  int64_t blocks = ceil_div64(n4, 256);
+  if (blocks > 2048 * 4) blocks = 2048 * 4;  // grid-stride the rest
+  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (const float*)bias, (const float*)residual, (float*)y, n4, C, HW / 4, relu);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,
+                                  const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
+                                  int64_t pos_rows, float eps, void* stream) {
+  const char* who = "wm2f_add_layernorm";
+  WM2F_REQUIRE(x && gamma && beta && out, "%s: null pointer", who);
+  WM2F_REQUIRE(C == 256, "%s: built for C = 256 only (got %d)", who, C);
+  WM2F_REQUIRE(rows > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE((out_plus_pos == nullptr) || (pos != nullptr && pos_rows > 0), "%s: out_plus_pos needs pos", who);
+  hipLaunchKernelGGL(add_layernorm256_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x, (const float*)residual, (const float*)gamma, (const float*)beta,
+                     (const float*)pos, (float*)out, (float*)out_plus_pos, rows, pos_rows > 0 ? pos_rows : 1, eps);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

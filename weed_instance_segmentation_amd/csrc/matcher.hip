@@ -8,9 +8,10 @@
 // covered by two launches (target sampling, cost), nothing syncs, and the caller copies ALL cost
 // matrices to the host once.
 //
-// Numerics: the sampled values are fp32 with grid_sample's arithmetic; the softplus / sigmoid
-// terms and every sum over the P points are carried in fp64, so the cost is within fp32 round-off
-// of the exact value -- assignments are stable under that.
+// Numerics: sampled values, softplus and sigmoid are fp32 (as in the reference); each thread sums
+// its ~49 of the P points in fp32, the cross-thread reduction and the cost arithmetic are fp64,
+// so the cost is within fp32 round-off of the exact value -- assignments are stable under that
+// (SURVEY.md F8).
 #include "common.h"
 
 namespace wm2f {
@@ -85,72 +86,82 @@ __global__ __launch_bounds__(256) void matcher_sample_targets_kernel(const T* __
   tm[lvl * tm_stride_lvl + (int64_t)t * P + p] = bilinear_zeros(tgt + (int64_t)t * Ht * Wt, Ht, Wt, pp[0], pp[1]);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
   return v;
 }
 
-// Cost rows of ONE image: block = (group of QG queries, level); loops over target chunks of TC.
-constexpr int kQG = 2, kTC = 8;
+// Cost rows of EVERY image and level in one launch: block = (group of QG queries, level, image);
+// loops over target chunks of TC.  Per-thread partial sums (P/256 ~ 49 terms) are fp32, the
+// cross-thread reduction and the cost arithmetic are fp64.
+constexpr int kQG = 2, kTC = 16, kMaxImg = 64;
+
+struct MatcherImages {
+  int off[kMaxImg + 1];  // target offsets per image
+};
 
 __global__ __launch_bounds__(256) void matcher_cost_kernel(
-    const float* __restrict__ mask_logits /* + b*Q*h*w */, const float* __restrict__ class_logits /* + b*Q*C1 */,
-    const float* __restrict__ tm /* + tgt_offset*P */, const int64_t* __restrict__ tgt_classes /* + tgt_offset */,
-    const float* __restrict__ points /* + b*P*2 */, float* __restrict__ cost /* + b*Q*Tmax */, int Q, int C1, int h,
-    int w, int P, int T, int Tmax, int64_t ml_stride_lvl, int64_t cl_stride_lvl, int64_t pts_stride_lvl,
-    int64_t tm_stride_lvl, int64_t cost_stride_lvl, float w_class, float w_mask, float w_dice) {
+    const float* __restrict__ mask_logits, const float* __restrict__ class_logits, const float* __restrict__ tm,
+    const int64_t* __restrict__ tgt_classes, const float* __restrict__ points, float* __restrict__ cost,
+    MatcherImages im, int B, int Q, int C1, int h, int w, int P, int Tsum, int Tmax, float w_class, float w_mask,
+    float w_dice) {
   constexpr int NV = kQG * kTC * 3 + kTC + kQG * 2;  // values reduced per chunk
-  __shared__ double red[4][NV];
-  const int lvl = blockIdx.y, q0 = blockIdx.x * kQG;
+  __shared__ float red[4][NV];
+  const int b = blockIdx.z, lvl = blockIdx.y, q0 = blockIdx.x * kQG;
+  const int t_begin = im.off[b], T = im.off[b + 1] - t_begin;
+  if (T <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* ml = mask_logits + lvl * ml_stride_lvl;
-  const float* pts = points + lvl * pts_stride_lvl;
-  const float* tml = tm + lvl * tm_stride_lvl;
+  const float* ml = mask_logits + ((int64_t)lvl * B + b) * Q * h * w;
+  const float* pts = points + ((int64_t)lvl * B + b) * P * 2;
+  const float* tml = tm + ((int64_t)lvl * Tsum + t_begin) * P;
+  const float* clb = class_logits + ((int64_t)lvl * B + b) * Q * C1;
+  float* costb = cost + ((int64_t)lvl * B + b) * Q * Tmax;
 
   for (int t0 = 0; t0 < T; t0 += kTC) {
-    double a_pos[kQG][kTC], a_neg[kQG][kTC], a_sig[kQG][kTC], s_t[kTC], s_neg[kQG], s_sig[kQG];
+    float a_pos[kQG][kTC], a_neg[kQG][kTC], a_sig[kQG][kTC], s_t[kTC], s_neg[kQG], s_sig[kQG];
 #pragma unroll
     for (int c = 0; c < kTC; ++c) {
-      s_t[c] = 0.0;
+      s_t[c] = 0.f;
 #pragma unroll
-      for (int qq = 0; qq < kQG; ++qq) a_pos[qq][c] = a_neg[qq][c] = a_sig[qq][c] = 0.0;
+      for (int qq = 0; qq < kQG; ++qq) a_pos[qq][c] = a_neg[qq][c] = a_sig[qq][c] = 0.f;
     }
 #pragma unroll
-    for (int qq = 0; qq < kQG; ++qq) s_neg[qq] = s_sig[qq] = 0.0;
+    for (int qq = 0; qq < kQG; ++qq) s_neg[qq] = s_sig[qq] = 0.f;
 
     for (int p = threadIdx.x; p < P; p += 256) {
-      const float px = pts[2 * p], py = pts[2 * p + 1];
-      double tv[kTC];
+      const float2 pt = *reinterpret_cast<const float2*>(pts + 2 * p);
+      float tv[kTC];
 #pragma unroll
       for (int c = 0; c < kTC; ++c) {
-        tv[c] = (t0 + c < T) ? (double)tml[(int64_t)(t0 + c) * P + p] : 0.0;
+        tv[c] = (t0 + c < T) ? tml[(int64_t)(t0 + c) * P + p] : 0.f;
         s_t[c] += tv[c];
       }
 #pragma unroll
       for (int qq = 0; qq < kQG; ++qq) {
         int qi = q0 + qq;
         if (qi > Q - 1) qi = Q - 1;
-        const double x = (double)bilinear_zeros(ml + (int64_t)qi * h * w, h, w, px, py);
-        const double e = exp(-fabs(x));
-        const double lg = log1p(e);
-        const double pos = fmax(-x, 0.0) + lg;  // BCEWithLogits(x, 1)
-        const double neg = fmax(x, 0.0) + lg;   // BCEWithLogits(x, 0)
-        const double sig = x >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+        const float x = bilinear_zeros(ml + (int64_t)qi * h * w, h, w, pt.x, pt.y);
+        const float e = expf(-fabsf(x));
+        const float lg = log1pf(e);
+        const float pos = fmaxf(-x, 0.f) + lg;  // BCEWithLogits(x, 1)
+        const float neg = fmaxf(x, 0.f) + lg;   // BCEWithLogits(x, 0)
+        const float r = 1.f / (1.f + e);
+        const float sig = x >= 0.f ? r : e * r;
         s_neg[qq] += neg;
         s_sig[qq] += sig;
 #pragma unroll
         for (int c = 0; c < kTC; ++c) {
-          a_pos[qq][c] += pos * tv[c];
-          a_neg[qq][c] += neg * tv[c];
-          a_sig[qq][c] += sig * tv[c];
+          a_pos[qq][c] = fmaf(pos, tv[c], a_pos[qq][c]);
+          a_neg[qq][c] = fmaf(neg, tv[c], a_neg[qq][c]);
+          a_sig[qq][c] = fmaf(sig, tv[c], a_sig[qq][c]);
         }
       }
     }
     // ---- block reduction: wave shuffles, then 4 partials through LDS
     int vi = 0;
-    auto put = [&](double v) {
-      v = wave_sum(v);
+    auto put = [&](float v) {
+      v = wave_sum_f(v);
       if (lane == 0) red[wave][vi] = v;
       ++vi;
     };
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(
       const int qq = threadIdx.x / kTC, c = threadIdx.x % kTC;
       const int qi = q0 + qq, t = t0 + c;
       if (qi < Q && t < T) {
-        auto R = [&](int i) { return red[0][i] + red[1][i] + red[2][i] + red[3][i]; };
+        auto R = [&](int i) { return (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i]; };
         const double apos = R((qq * kTC + c) * 3 + 0), aneg = R((qq * kTC + c) * 3 + 1);
         const double asig = R((qq * kTC + c) * 3 + 2);
         const double st = R(kQG * kTC * 3 + c);
@@ -182,19 +193,19 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(
         const double cost_mask = (apos + (sneg - aneg)) / (double)P;
         const double cost_dice = 1.0 - (2.0 * asig + 1.0) / (ssig + st + 1.0);
         // -softmax(class_logits)[target class], HF:445-449
-        const float* cl = class_logits + lvl * cl_stride_lvl + (int64_t)qi * C1;
+        const float* cl = clb + (int64_t)qi * C1;
         double mx = -1e300;
         for (int k2 = 0; k2 < C1; ++k2) mx = fmax(mx, (double)cl[k2]);
         double den = 0.0;
         for (int k2 = 0; k2 < C1; ++k2) den += exp((double)cl[k2] - mx);
-        const int64_t tc = tgt_classes[t];
+        const int64_t tc = tgt_classes[t_begin + t];
         const double prob = (tc >= 0 && tc < C1) ? exp((double)cl[tc] - mx) / den : 0.0;
-        double cst = (double)w_mask * cost_mask - (double)w_class * prob + (double)w_dice * cost_dice;
+        const double cst = (double)w_mask * cost_mask - (double)w_class * prob + (double)w_dice * cost_dice;
         float cf = (float)cst;
         cf = fminf(cf, 1e10f);
         cf = fmaxf(cf, -1e10f);
         if (cf != cf) cf = 0.f;
-        cost[lvl * cost_stride_lvl + (int64_t)qi * Tmax + t] = cf;
+        costb[(int64_t)qi * Tmax + t] = cf;
       }
     }
     __syncthreads();
@@ -231,6 +242,9 @@ extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logi
   float* tm = (float*)workspace;
   const int64_t tm_stride_lvl = (int64_t)Tsum * P;
   const int64_t pts_stride_lvl = (int64_t)B * P * 2;
+  WM2F_REQUIRE(B <= kMaxImg, "%s: at most %d images per call", who, kMaxImg);
+  MatcherImages im;
+  for (int b = 0; b <= B; ++b) im.off[b] = tgt_offset[b];
   for (int b = 0; b < B; ++b) {
     const int T = tgt_offset[b + 1] - tgt_offset[b];
     WM2F_REQUIRE(T >= 0 && T <= Tmax && T <= 65535, "%s: image %d has %d targets (Tmax=%d)", who, b, T, Tmax);
@@ -246,14 +260,11 @@ extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logi
       hipLaunchKernelGGL(matcher_sample_targets_kernel<uint8_t>, ga, dim3(256), 0, st,
                          (const uint8_t*)tgt_masks + (int64_t)tgt_offset[b] * Ht * Wt, pts_b, tm_b, Ht, Wt, P,
                          pts_stride_lvl, tm_stride_lvl);
-    dim3 gb(ceil_div(Q, kQG), NL);
-    hipLaunchKernelGGL(matcher_cost_kernel, gb, dim3(256), 0, st,
-                       (const float*)mask_logits + (int64_t)b * Q * h * w,
-                       (const float*)class_logits + (int64_t)b * Q * C1, tm_b,
-                       (const int64_t*)tgt_classes + tgt_offset[b], pts_b, (float*)cost + (int64_t)b * Q * Tmax, Q, C1,
-                       h, w, P, T, Tmax, (int64_t)B * Q * h * w, (int64_t)B * Q * C1, pts_stride_lvl, tm_stride_lvl,
-                       (int64_t)B * Q * Tmax, w_class, w_mask, w_dice);
   }
+  dim3 gb(ceil_div(Q, kQG), NL, B);
+  hipLaunchKernelGGL(matcher_cost_kernel, gb, dim3(256), 0, st, (const float*)mask_logits,
+                     (const float*)class_logits, (const float*)tm, (const int64_t*)tgt_classes,
+                     (const float*)points, (float*)cost, im, B, Q, C1, h, w, P, Tsum, Tmax, w_class, w_mask, w_dice);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }

@@ -241,7 +241,7 @@ static int fill_levels(LevelInfo& lv, const int32_t* level_hw, int L, int S, con
 template <bool FUSED>
 int launch_tiled(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
                  int Q, int heads, int L, int P, int margin, int threads, void* stream, const char* who,
-                 bool* handled, int mode);
+                 bool* handled, int mode, int a_qstride, int b_qstride);
 
 struct LaunchGeom {
   int64_t n_pairs;
@@ -276,7 +276,7 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
     bool handled = false;
     if (int rc = launch_tiled<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, margin,
                                      512, stream, who, &handled,
-                                     variant >= 12 && variant % 10 == 2 ? variant / 10 : 0))
+                                     variant >= 12 && variant % 10 == 2 ? variant / 10 : 0, 0, 0))
       return rc;
     if (handled) return WM2F_OK;
   }
@@ -330,6 +330,30 @@ extern "C" int wm2f_msdeform_fwd_v(const void* value, const void* a, const void*
                             "wm2f_msdeform_fwd_v", variant, margin);
   return launch_fwd<false>(value, a, b, nullptr, out, level_hw, B, S, Q, heads, D, L, P, dtype, stream,
                            "wm2f_msdeform_fwd_v", variant, margin);
+}
+
+extern "C" int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* out,
+                                              const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L,
+                                              int P, int dtype, int margin, void* stream) {
+  const char* who = "wm2f_msdeform_fused_packed_fwd";
+  WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
+  WM2F_REQUIRE(value && packed && out && level_hw, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && S > 0 && Q > 0 && heads > 0 && P > 0, "%s: non-positive size", who);
+  LevelInfo lv;
+  if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  const int row = heads * L * P * 3;  // [offsets heads*L*P*2 | logits heads*L*P]
+  bool handled = false;
+  if (D == 32) {
+    const float* a = (const float*)packed;
+    if (int rc = launch_tiled<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, margin, 512,
+                                    stream, who, &handled, 0, row, row))
+      return rc;
+  }
+  if (!handled) {
+    set_error("%s: needs D=32, P=4, Q==S, L<=4 and windows that fit LDS; use wm2f_msdeform_fused_fwd", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  return WM2F_OK;
 }
 
 extern "C" int wm2f_msdeform_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out,

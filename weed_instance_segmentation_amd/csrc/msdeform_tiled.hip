@@ -40,6 +40,7 @@ struct TileGeom {
   int lds_off4[kMaxLv];              // window base in LDS, in float4 units (padded to 8 pixels)
   int lv_tab_off4;                   // 16-int level table behind the windows
   int order;                         // 0 = (image, head)-major ids, 1 = heads innermost
+  int a_qstride, b_qstride;          // floats between consecutive queries in the two operand arrays
 };
 
 __device__ __forceinline__ int ceil_div_i(int a, int b) {  // b > 0, a may be negative
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(kTiledThreads) void msdeform_tiled_fwd_kernel(const
     int q = st + o.qyi * Wq + o.qxi;
     if (q > Q - 1) q = Q - 1;
     o.pair = ((int64_t)b * Q + q) * heads + h;
-    const float* ap = a_in + o.pair * (NL * P * 2);
-    const float* bp = b_in + o.pair * (NL * P);
+    const float* ap = a_in + ((int64_t)b * Q + q) * g.a_qstride + h * (NL * P * 2);
+    const float* bp = b_in + ((int64_t)b * Q + q) * g.b_qstride + h * (NL * P);
     if (MODE == 3 || MODE == 5) {  // ablation: synthetic operands, no global loads
 #pragma unroll
       for (int i = 0; i < NL * P / 2; ++i) o.lc[i] = make_float4(0.3f * i - 1.f, 0.7f - 0.2f * i, 0.1f * (qi & 15) - 2.f, 1.5f);
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(kTiledThreads) void msdeform_tiled_fwd_kernel(const
     const QueryOps<NL, P> cur = nxt;
     nxt = load_ops(qi + kSlots);  // prefetch the next query's operands under this query's sampling
     const int64_t pair = cur.pair;
-    const float* ap = a_in + pair * (NL * P * 2);
-    const float* bp = b_in + pair * (NL * P);
+    const float* ap = a_in + (pair / heads) * g.a_qstride + h * (NL * P * 2);
+    const float* bp = b_in + (pair / heads) * g.b_qstride + h * (NL * P);
 
     float wts[NL * P];
 #pragma unroll
@@ -403,13 +404,15 @@ static TiledPlan plan_tiled(const int32_t* level_hw, int L, int margin) {
 template <bool FUSED>
 int launch_tiled(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
                  int Q, int heads, int L, int P, int margin, int threads, void* stream, const char* who,
-                 bool* handled, int mode) {
+                 bool* handled, int mode, int a_qstride, int b_qstride) {
   *handled = false;
   if (P != 4 || L < 1 || L > kMaxLv || margin < 0) return WM2F_OK;
   if ((int64_t)Q != S) return WM2F_OK;  // the tiling assumes queries == value tokens (encoder self-attention)
   TiledPlan p = plan_tiled(level_hw, L, margin);
   if (!p.ok) return WM2F_OK;
-  p.g.order = (mode == 6) ? 0 : 1;  // default: heads innermost (measured 4 % faster); mode 6 = slab-major
+  p.g.order = (mode == 6) ? 0 : 1;
+  p.g.a_qstride = a_qstride > 0 ? a_qstride : heads * L * P * 2;
+  p.g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;  // default: heads innermost (measured 4 % faster); mode 6 = slab-major
   const int64_t n_logical = (int64_t)B * heads * p.g.tiles_x * p.g.tiles_y;
   if (n_logical > (1 << 30)) return WM2F_OK;
   const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
@@ -449,8 +452,8 @@ int launch_tiled(const void* value, const void* a, const void* b, void* out, con
 
 // explicit instantiations used by msdeform.hip
 template int launch_tiled<false>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int,
-                                 int, int, int, int, void*, const char*, bool*, int);
+                                 int, int, int, int, void*, const char*, bool*, int, int, int);
 template int launch_tiled<true>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
-                                int, int, int, void*, const char*, bool*, int);
+                                int, int, int, void*, const char*, bool*, int, int, int);
 
 }  // namespace wm2f

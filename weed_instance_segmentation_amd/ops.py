@@ -132,6 +132,30 @@ def ms_deform_attn_fused(value: torch.Tensor, level_hw, offsets: torch.Tensor, l
     return out
 
 
+def ms_deform_attn_fused_packed(value, level_hw, packed, ref, heads: int, L: int, P: int, margin: int = 4):
+    """Inference K1 fed by ONE merged projection: packed (B,Q,heads*L*P*3) = [offsets | logits] per token.
+    Falls back to the two-array fused kernel (after splitting) where the LDS-window kernel does not apply."""
+    if torch.is_grad_enabled() and (value.requires_grad or packed.requires_grad):
+        raise RuntimeError("ms_deform_attn_fused_packed has no backward; use ms_deform_attn when training")
+    value, packed = _req(value, "value"), _req(packed, "packed")
+    B, S, H, D = value.shape
+    Q = packed.shape[1]
+    if H != heads or packed.shape != (B, Q, heads * L * P * 3):
+        raise ValueError(f"ms_deform_attn_fused_packed: value {tuple(value.shape)} packed {tuple(packed.shape)}")
+    out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
+    lv = host_i32([x for hw in level_hw for x in hw])
+    with torch.cuda.device(value.device):
+        rc = _timed("msdeform_fused_fwd", value, lambda: load().wm2f_msdeform_fused_packed_fwd(
+            _p(value), _p(packed), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32, int(margin), _stream(value)))
+    if rc == -2:  # WM2F_EUNSUPPORTED: shape outside the LDS-window kernel -> direct-gather HIP kernel
+        n_off = heads * L * P * 2
+        off = packed[..., :n_off].reshape(B, Q, heads, L, P, 2).contiguous()
+        logits = packed[..., n_off:].reshape(B, Q, heads, L * P).contiguous()
+        return ms_deform_attn_fused(value, level_hw, off, logits, ref)
+    check(rc, "wm2f_msdeform_fused_packed_fwd")
+    return out
+
+
 def ms_deform_attn_variant(value, level_hw, a, b, ref=None, fused=False, variant=0, margin=4) -> torch.Tensor:
     """K1 with the kernel variant exposed (no autograd): variant 0 auto, 1 direct gather, 2 LDS windows.
     fused=False: a = loc, b = attn_w.  fused=True: a = raw offsets, b = raw logits, ref (Q,L,2)."""
@@ -322,3 +346,42 @@ def point_sample(feat: torch.Tensor, pts: torch.Tensor, map_index: torch.Tensor 
     """sample_point (HF:245-274) for single-channel maps: feat (N,H,W), pts (M,P,2) in [0,1] (x,y) -> (M,P).
     Row m samples feat[map_index[m]] (int32) -- or feat[m] when map_index is None."""
     return _PointSample.apply(feat, pts, map_index)
+
+
+# ----------------------------------------------------------------------------------------- fused passes
+def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor | None = None, relu: bool = True):
+    """In place: x <- act(x + bias[c] (+ residual)) for an NCHW tensor (inference, no autograd)."""
+    if not x.is_contiguous():
+        raise ValueError("bias_act_: x must be NCHW-contiguous")
+    _req(x, "x"), _req(bias, "bias")
+    N, C, H, W = x.shape
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("bias_act_: residual shape")
+    with torch.cuda.device(x.device):
+        check(load().wm2f_bias_act(_p(x), _p(bias), _p(residual), _p(x), N, C, H * W, 1 if relu else 0, _stream(x)),
+              "wm2f_bias_act")
+    return x
+
+
+def add_layernorm(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None = None):
+    """LayerNorm(x + residual) over the last dim (= 256); with `pos` (rows_per_image, 256) also returns
+    out + pos broadcast over the batch.  Inference only (no autograd)."""
+    x, gamma, beta = _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if residual is not None:
+        residual = _req(residual, "residual")
+    out = torch.empty_like(x)
+    out_pos, pos_rows = None, 0
+    if pos is not None:
+        pos = _req(pos, "pos")
+        pos_rows = pos.numel() // C
+        if rows % pos_rows:
+            raise ValueError("add_layernorm: pos rows do not divide x rows")
+        out_pos = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(load().wm2f_add_layernorm(_p(x), _p(residual), _p(gamma), _p(beta), _p(pos), _p(out), _p(out_pos), rows, C,
+                                        pos_rows, float(eps), _stream(x)), "wm2f_add_layernorm")
+    return (out, out_pos) if pos is not None else out
