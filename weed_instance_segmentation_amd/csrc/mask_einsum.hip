@@ -30,15 +30,17 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 constexpr int kStripPix = 64;   // pixels per wave strip (4 column tiles x 16)
 constexpr int kEinsumWaves = 8; // waves per workgroup (2 per SIMD)
 
-template <int MT>
+// MT row tiles run on the matrix cores; REM (0 or 4) further query rows run on the VALU pipe, which is
+// otherwise idle under the MFMAs: Q = 100 = 6*16 + 4 would waste 75 % of a 7th row tile.
+template <int MT, int REM>
 __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(const float* __restrict__ emb,
                                                                               const float* __restrict__ pix,
                                                                               float* __restrict__ out, int Q, int C,
                                                                               int HW, int q_chunks) {
-  extern __shared__ __attribute__((aligned(16))) float e_lds[];  // [MT][C/16][64][4]
+  extern __shared__ __attribute__((aligned(16))) float e_lds[];  // [MT][C/16][64][4], then [C/16][4][4][4] (REM)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y / q_chunks, chunk = blockIdx.y % q_chunks;
-  const int q0 = chunk * (MT * 16);
+  const int q0 = chunk * (MT * 16 + REM);
   const int S16 = C / 16, C4 = C / 4;
 
   // ---- stage emb rows q0 .. q0+16*MT-1 into LDS, fragment order, zero rows beyond Q
@@ -50,6 +52,20 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)(q0 + r) * C + col);
     *reinterpret_cast<float4*>(e_lds + ((int64_t)(mt * S16 + s) * 64 + (g * 16 + m)) * 4) = v;
+  }
+  // remainder rows, laid out [super-step][lane group g][k-step t][row]: a lane reads the 4 rows of its
+  // channel 16s+4g+t as one float4 (same address for the 16 lanes of a group -> broadcast)
+  float* e_rem = e_lds + MT * 16 * C;
+  if (REM) {
+    for (int idx = tid; idx < C; idx += kEinsumWaves * kWave) {  // idx = channel
+      float4 v;
+      const int qr = q0 + MT * 16;
+      v.x = (qr + 0 < Q) ? eb[(int64_t)(qr + 0) * C + idx] : 0.f;
+      v.y = (qr + 1 < Q) ? eb[(int64_t)(qr + 1) * C + idx] : 0.f;
+      v.z = (qr + 2 < Q) ? eb[(int64_t)(qr + 2) * C + idx] : 0.f;
+      v.w = (qr + 3 < Q) ? eb[(int64_t)(qr + 3) * C + idx] : 0.f;
+      *reinterpret_cast<float4*>(e_rem + idx * 4) = v;  // channel-major == [s][g][t] order
+    }
   }
   __syncthreads();
 
@@ -76,6 +92,9 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 rem[4];  // rem[row][pixel j]: partial sums over THIS lane group's channels
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rem[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // Two named register sets (b0 / b1) and a 2x unrolled loop: the loads of super-step s+1 are
   // issued before the MFMAs of super-step s and waited for with a COUNTED vmcnt only when used.
@@ -90,6 +109,11 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       a[mt] = *reinterpret_cast<const f32x4*>(e_lds + ((mt * S16 + s) * 64 + lane) * 4);
+    f32x4 er[4];
+    if (REM) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) er[t] = *reinterpret_cast<const f32x4*>(e_rem + ((s * 4 + g) * 4 + t) * 4);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -97,6 +121,10 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], bb[t][j], acc[mt][j], 0, 0, 0);
+      }
+      if (REM) {  // 16 VALU FMAs per k-step, hidden in the MFMA issue gaps
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rem[r] = __builtin_elementwise_fma((f32x4){er[t][r], er[t][r], er[t][r], er[t][r]}, bb[t], rem[r]);
       }
     }
   };
@@ -131,6 +159,22 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
                                              (q0 + mt * 16 + r) * row_bytes, 0);
     }
   }
+  if (REM) {  // sum the 4 lane groups' channel partials; group 0 stores rows q0+16*MT .. +3
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = rem[r][j];
+        x += __shfl_xor(x, 16, kWave);
+        x += __shfl_xor(x, 32, kWave);
+        rem[r][j] = x;
+      }
+    const uint32_t voff_r = (pvalid && g == 0) ? (uint32_t)(p0 * 4) : kOob;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rem[r]), out_rsrc, voff_r,
+                                             (q0 + MT * 16 + r) * row_bytes, 0);
+  }
 }
 
 }  // namespace wm2f
@@ -147,19 +191,29 @@ extern "C" int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out,
   WM2F_REQUIRE(HW % 4 == 0, "%s: HW=%d must be a multiple of 4", who, HW);
   WM2F_REQUIRE((int64_t)C * HW * 4 < (1ll << 31) && (int64_t)(Q + 16) * HW * 4 < (1ll << 31),
                "%s: one image's pix / out slab must stay below 2 GiB (32-bit buffer offsets)", who);
-  // row tiles per pass: as many as fit 160 KiB of LDS, at most 7 (accumulator registers)
-  int mt_cap = (160 * 1024) / (16 * C * 4);
+  // Query rows per pass: up to 7 MFMA row tiles (accumulator registers / 160 KiB of LDS); when the last
+  // chunk leaves 1..4 rows over a multiple of 16 they go to the VALU side path instead of a padded tile.
+  int mt_cap = (160 * 1024 - 16 * C) / (16 * C * 4);
   if (mt_cap > 7) mt_cap = 7;
   WM2F_REQUIRE(mt_cap >= 1, "%s: C=%d too large for the LDS-resident emb tile", who, C);
-  const int q_chunks = ceil_div(Q, 16 * mt_cap);
-  const int MT = ceil_div(ceil_div(Q, q_chunks), 16);
+  int q_chunks = ceil_div(Q, 16 * mt_cap);
+  int rows_per_chunk = ceil_div(Q, q_chunks);
+  int MT = rows_per_chunk / 16, REM = 0;
+  const int left = rows_per_chunk - MT * 16;
+  if (left > 0 && left <= 4 && MT >= 1 && MT <= 6 && Q == q_chunks * rows_per_chunk) REM = 4;  // exact split only
+  else if (left > 0) MT += 1;
+  if (MT > mt_cap) {  // fall back to plain padding with one more chunk
+    q_chunks += 1;
+    MT = ceil_div(ceil_div(Q, q_chunks), 16);
+    REM = 0;
+  }
   const int n_strips = ceil_div(HW, kStripPix);
   dim3 grid(ceil_div(n_strips, kEinsumWaves), B * q_chunks);
-  const size_t lds = (size_t)MT * 16 * C * 4;
+  const size_t lds = (size_t)MT * 16 * C * 4 + (REM ? (size_t)C * 16 : 0);
   hipStream_t st = (hipStream_t)stream;
-#define WM2F_LAUNCH(MTv)                                                                                     \
-  case MTv: {                                                                                                \
-    auto kfn = mask_einsum_fwd_kernel<MTv>;                                                                  \
+#define WM2F_LAUNCH(MTv, REMv)                                                                               \
+  if (MT == MTv && REM == REMv) {                                                                            \
+    auto kfn = mask_einsum_fwd_kernel<MTv, REMv>;                                                            \
     if (lds > 64 * 1024) {                                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) {                                                                                 \
@@ -169,14 +223,17 @@ extern "C" int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out,
     }                                                                                                        \
     hipLaunchKernelGGL(kfn, grid, dim3(kEinsumWaves* kWave), lds, st, (const float*)emb, (const float*)pix,  \
                        (float*)out, Q, C, HW, q_chunks);                                                     \
-  } break;
-  switch (MT) {
-    WM2F_LAUNCH(1) WM2F_LAUNCH(2) WM2F_LAUNCH(3) WM2F_LAUNCH(4) WM2F_LAUNCH(5) WM2F_LAUNCH(6) WM2F_LAUNCH(7)
-    default:
-      set_error("%s: internal: MT=%d", who, MT);
-      return WM2F_EINVAL;
+    launched = true;                                                                                         \
   }
+  bool launched = false;
+  WM2F_LAUNCH(1, 0) WM2F_LAUNCH(2, 0) WM2F_LAUNCH(3, 0) WM2F_LAUNCH(4, 0) WM2F_LAUNCH(5, 0) WM2F_LAUNCH(6, 0)
+  WM2F_LAUNCH(7, 0) WM2F_LAUNCH(1, 4) WM2F_LAUNCH(2, 4) WM2F_LAUNCH(3, 4) WM2F_LAUNCH(4, 4) WM2F_LAUNCH(5, 4)
+  WM2F_LAUNCH(6, 4)
 #undef WM2F_LAUNCH
+  if (!launched) {
+    set_error("%s: internal: MT=%d REM=%d", who, MT, REM);
+    return WM2F_EINVAL;
+  }
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
