@@ -146,6 +146,30 @@ def test_k1_backward(ops):
     torch.testing.assert_close(l1.grad.cpu(), l0.grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("shapes,B", [([(8, 8), (16, 16), (32, 32)], 2), ([(5, 7), (10, 14), (20, 28)], 1),
+                                      ([(12, 20), (24, 40)], 2)])
+def test_k1_backward_local_offsets(ops, shapes, B):
+    """LDS-window backward in its fast regime (offsets of a few pixels) plus one far outlier."""
+    H, D, L, P = 8, 32, len(shapes), 4
+    g = torch.Generator().manual_seed(13)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * 2.0
+    off[0, 5, 1, 0, 2] = torch.tensor([-30.0, 25.0])
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = (ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+    w = torch.softmax(torch.randn(B, S, H, L * P, generator=g), -1).view(B, S, H, L, P).contiguous()
+    go = torch.randn(B, S, H * D, generator=g)
+    v0, l0, w0 = value.clone().requires_grad_(), loc.clone().requires_grad_(), w.clone().requires_grad_()
+    O.msdeform_attn_core(v0, shapes, l0, w0).backward(go)
+    v1, l1, w1 = dev(value).requires_grad_(), dev(loc).requires_grad_(), dev(w).requires_grad_()
+    ops.ms_deform_attn(v1, shapes, l1, w1).backward(dev(go))
+    torch.testing.assert_close(v1.grad.cpu(), v0.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(w1.grad.cpu(), w0.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(l1.grad.cpu(), l0.grad, rtol=1e-3, atol=2e-4)
+
+
 # ----------------------------------------------------------------------------------------- K3
 def test_k3_golden(ops):
     g = load_golden("k3_mask_predictor.npz")

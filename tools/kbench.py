@@ -39,7 +39,7 @@ def main():
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device="cpu").manual_seed(0)
     res = {}
-    if "k1" in only or "k1f" in only or "k1v" in only or "k1t" in only:
+    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1b")):
         value = torch.randn(B, S, H, D, device=dev)
         # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
@@ -64,6 +64,14 @@ def main():
                 r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=variant, margin=margin), a.iters)
                 r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
                 res[f"k1_fused_variant{variant}_margin{margin}"] = r
+        if "k1b" in only:  # backward
+            vv, ll, ww_ = value.clone().requires_grad_(), loc.clone().requires_grad_(), aw.clone().requires_grad_()
+            go = torch.randn(B, S, H * D, device=dev)
+            def fb():
+                o = ops.ms_deform_attn(vv, shapes, ll, ww_)
+                o.backward(go)
+                vv.grad = ll.grad = ww_.grad = None
+            res["k1_fwd_plus_bwd"] = timeit(fb, a.iters)
         if "k1t" in only:  # one variant only, for PMC runs
             r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=2, margin=4), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)

@@ -243,6 +243,11 @@ int launch_tiled(const void* value, const void* a, const void* b, void* out, con
                  int Q, int heads, int L, int P, int margin, int threads, void* stream, const char* who,
                  bool* handled, int mode, int a_qstride, int b_qstride);
 
+// msdeform_tiled_bwd.hip
+int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
+                     void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
+                     int margin, void* stream, const char* who, bool* handled);
+
 struct LaunchGeom {
   int64_t n_pairs;
   int n_blocks, blocks_per_xcd, grid;
@@ -367,6 +372,13 @@ extern "C" int wm2f_msdeform_bwd(const void* value, const void* loc, const void*
   WM2F_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {8,16,32,64}", who, D);
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  if (D == 32) {  // LDS-window backward: the scatter is absorbed on chip
+    bool handled = false;
+    if (int rc = launch_tiled_bwd(value, loc, attn_w, grad_out, grad_value, grad_loc, grad_attn_w, level_hw, B, S, Q,
+                                  heads, L, P, 4, stream, who, &handled))
+      return rc;
+    if (handled) return WM2F_OK;
+  }
   const LaunchGeom g = geom(B, Q, heads, D);
   hipStream_t st = (hipStream_t)stream;
 #define WM2F_LAUNCH_BWD(DD)                                                                                  \

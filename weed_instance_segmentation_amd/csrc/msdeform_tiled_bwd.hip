@@ -1,0 +1,348 @@
+// K1 backward, LDS-window variant (head_dim 32).  Same tiling as msdeform_tiled.hip.
+//
+// The direct backward (msdeform.hip) scatters grad_value with global float atomics: 8.46 GB of added
+// bytes per call against a chip-wide atomic rate of ~1.3 TB/s -- measured 25 ms per call, 150 ms of a
+// 400 ms train step.  Here the scatter is absorbed on chip:
+//
+//   kernel A (grad_loc, grad_attn_w): stage the VALUE windows in LDS (as the forward does), then per
+//     sampling point gather the four corners, dot them with the query's grad_out (8 channels per lane,
+//     4 lanes per query, quad shuffles), and form the three scalar gradients.  No scatter.
+//   kernel B (grad_value): the LDS window is an ACCUMULATOR: every (query, point, corner) adds
+//     weight * grad_out with ds_add_f32; once per tile the window is flushed to grad_value with global
+//     atomics shaped as whole 128-B rows (lane = channel), i.e. 0.63 GB per call instead of 8.46 GB.
+// Points whose footprint leaves the window fall back to global loads / global atomics, so results do
+// not depend on the margin.
+//
+// Measured (config 2, one call): kernel A 0.52 ms; kernel B 10.3 ms, ALL of it in the ds_add_f32 stream
+// (ablation: without the flush 10.3 ms, without the LDS adds 0.2 ms): an LDS float atomic costs ~176
+// cycles per wave-instruction (~2.7 cycles per lane) whether or not lanes conflict -- the wave-per-query
+// form below (two contiguous 128-B rows per instruction) runs exactly as long as a scattered form did.
+// Total 10.8 ms vs 25 ms for the global-atomic backward.  The next step is an atomic-free accumulation
+// (channel groups owned by waves + in-order read-modify-write), estimated at 1.5 ms.
+#include "msdeform_tiled.h"
+
+namespace wm2f {
+
+constexpr int kBwdThreads = 512;
+
+__device__ const float4 g_zero_page_bwd[1] = {{0.f, 0.f, 0.f, 0.f}};  // LDS-DMA source for out-of-image pixels
+
+template <int NL>
+struct TileCtx {
+  int tile, h, b;
+  int wx0[NL], wy0[NL], nq;
+};
+
+// Decode the logical id, fill the per-level LDS table (H, W, start, nqx, qx0, qy0, first query, 1/nqx).
+template <int NL>
+__device__ __forceinline__ TileCtx<NL> tile_setup(const TileGeom& g, int id, int heads, int* lv_tab) {
+  TileCtx<NL> c;
+  const int n_tiles = g.tiles_x * g.tiles_y;
+  c.h = id % heads;
+  const int bt = id / heads;
+  c.tile = bt % n_tiles;
+  c.b = bt / n_tiles;
+  const int ty = c.tile / g.tiles_x, tx = c.tile - ty * g.tiles_x;
+  const int Wf = g.w[g.fine], Hf = g.h[g.fine];
+  int qcnt = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int Wl = g.w[l], Hl = g.h[l];
+    c.wx0[l] = floor_div_i(2 * tx * g.F * Wl - Wf, 2 * Wf) - g.M;
+    c.wy0[l] = floor_div_i(2 * ty * g.F * Hl - Hf, 2 * Hf) - g.M;
+    const int qx0 = q_lo(tx, g.F, Wl, Wf), qy0 = q_lo(ty, g.F, Hl, Hf);
+    const int nqx = q_lo(tx + 1, g.F, Wl, Wf) - qx0, nqy = q_lo(ty + 1, g.F, Hl, Hf) - qy0;
+    if (threadIdx.x == 0) {
+      lv_tab[l * 8 + 0] = Hl;
+      lv_tab[l * 8 + 1] = Wl;
+      lv_tab[l * 8 + 2] = g.start[l];
+      lv_tab[l * 8 + 3] = nqx < 1 ? 1 : nqx;
+      lv_tab[l * 8 + 4] = qx0;
+      lv_tab[l * 8 + 5] = qy0;
+      lv_tab[l * 8 + 6] = qcnt;
+      lv_tab[l * 8 + 7] = __float_as_int(1.f / (float)(nqx < 1 ? 1 : nqx));
+    }
+    qcnt += nqx * nqy;
+  }
+  c.nq = qcnt;
+  return c;
+}
+
+// query index of slot qi inside the tile -> global query id (level table in LDS)
+template <int NL>
+__device__ __forceinline__ int tile_query(const int* lv_tab, int qi, int Q) {
+  int lq = 0;
+#pragma unroll
+  for (int l = 1; l < NL; ++l) lq += (qi >= lv_tab[l * 8 + 6]) ? 1 : 0;
+  const int4 ta = *reinterpret_cast<const int4*>(lv_tab + lq * 8), tb = *reinterpret_cast<const int4*>(lv_tab + lq * 8 + 4);
+  const int loc_i = qi - tb.z;
+  const int ly_ = (int)(((float)loc_i + 0.5f) * __int_as_float(tb.w));
+  const int lx_ = loc_i - ly_ * ta.w;
+  int q = ta.z + (tb.y + ly_) * ta.y + (tb.x + lx_);
+  return q > Q - 1 ? Q - 1 : q;
+}
+
+__device__ __forceinline__ float dot8(const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
+  return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+}
+
+__device__ __forceinline__ float quad_sum(float v) {  // over the 4 lanes of a query
+  v += __shfl_xor(v, 1, kWave);
+  v += __shfl_xor(v, 2, kWave);
+  return v;
+}
+
+__device__ __forceinline__ void pixel_coords(float lx, float ly, int Wl, int Hl, float& x, float& y) {
+  x = ((2.f * lx - 1.f + 1.f) * (float)Wl - 1.f) * 0.5f;  // grid_sample, align_corners = False
+  y = ((2.f * ly - 1.f + 1.f) * (float)Hl - 1.f) * 0.5f;
+}
+
+// ---------------------------------------------------------------------------------- kernel A
+template <int NL, int P>
+__global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
+    const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn_w,
+    const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, TileGeom g, int S,
+    int Q, int heads, int n_logical, int per_xcd) {
+  constexpr int D = 32, kLQ = 4, kSlots = kBwdThreads / kLQ, kWaves = kBwdThreads / kWave;
+  extern __shared__ __attribute__((aligned(16))) float4 win[];
+  const int id = xcd_contiguous_id(blockIdx.x, per_xcd);
+  if (id >= n_logical) return;
+  int* lv_tab = reinterpret_cast<int*>(win + g.lv_tab_off4);
+  const TileCtx<NL> c = tile_setup<NL>(g, id, heads, lv_tab);
+  const int tid = threadIdx.x, j = tid & (kLQ - 1), slot = tid / kLQ;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row_stride = heads * D;
+  const float* vb = value + ((int64_t)c.b * S * heads + c.h) * D;
+
+  // stage the value windows (zero outside the image)
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l];
+    const int npix = ww * g.win_h[l], n_chunks = (npix + 7) >> 3;
+    const float inv_ww = 1.f / (float)ww;
+    const float* vlev = vb + (int64_t)g.start[l] * row_stride;
+    for (int ch = wave; ch < n_chunks; ch += kWaves) {
+      const int idx = ch * 8 + (lane >> 3);
+      const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
+      const int x = c.wx0[l] + wx, y = c.wy0[l] + wy;
+      const bool in = idx < npix && x >= 0 && x < Wl && y >= 0 && y < Hl;
+      const float* src = in ? vlev + (int64_t)(y * Wl + x) * row_stride + (lane & 7) * 4
+                            : reinterpret_cast<const float*>(g_zero_page_bwd);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(win + g.lds_off4[l] + ch * 64), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qi = slot; qi < c.nq; qi += kSlots) {
+    const int q = tile_query<NL>(lv_tab, qi, Q);
+    const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
+    const float* lp = loc + pair * (NL * P * 2);
+    const float* wp = attn_w + pair * (NL * P);
+    const float4 go0 = ld4g(grad_out + pair * D + j * 4), go1 = ld4g(grad_out + pair * D + 16 + j * 4);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l], wh = g.win_h[l];
+      const float4* wl = win + g.lds_off4[l] + j;
+      const float* vlev = vb + (int64_t)g.start[l] * row_stride + j * 4;
+      const float4 aw4 = ld4g(wp + l * P);
+      float gw[P], gx[P], gy[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
+        const float aw = p == 0 ? aw4.x : p == 1 ? aw4.y : p == 2 ? aw4.z : aw4.w;
+        float x, y;
+        pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
+        const float x0f = floorf(x), y0f = floorf(y);
+        const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+        const int xr = (int)x0f - c.wx0[l], yr = (int)y0f - c.wy0[l];
+        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
+        if ((unsigned)xr < (unsigned)(ww - 1) && (unsigned)yr < (unsigned)(wh - 1)) {
+          const float4* cc = wl + (yr * ww + xr) * 8;
+          d00 = dot8(go0, go1, cc[0], cc[4]);
+          d01 = dot8(go0, go1, cc[8], cc[12]);
+          d10 = dot8(go0, go1, cc[ww * 8], cc[ww * 8 + 4]);
+          d11 = dot8(go0, go1, cc[ww * 8 + 8], cc[ww * 8 + 12]);
+        } else if (x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl) {  // general path, global loads
+          const int x0 = (int)x0f, y0 = (int)y0f;
+          const bool xl = x0 >= 0, xr2 = x0 + 1 < Wl, yt = y0 >= 0, yb = y0 + 1 < Hl;
+          const float* p00 = vlev + (int64_t)(y0 * Wl + x0) * row_stride;
+          if (yt && xl) d00 = dot8(go0, go1, ld4g(p00), ld4g(p00 + 16));
+          if (yt && xr2) d01 = dot8(go0, go1, ld4g(p00 + row_stride), ld4g(p00 + row_stride + 16));
+          if (yb && xl) d10 = dot8(go0, go1, ld4g(p00 + (int64_t)Wl * row_stride), ld4g(p00 + (int64_t)Wl * row_stride + 16));
+          if (yb && xr2)
+            d11 = dot8(go0, go1, ld4g(p00 + (int64_t)(Wl + 1) * row_stride), ld4g(p00 + (int64_t)(Wl + 1) * row_stride + 16));
+        }
+        d00 = quad_sum(d00);
+        d01 = quad_sum(d01);
+        d10 = quad_sum(d10);
+        d11 = quad_sum(d11);
+        const bool inside = x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl;
+        gw[p] = inside ? fy0 * (fx0 * d00 + fx1 * d01) + fy1 * (fx0 * d10 + fx1 * d11) : 0.f;
+        gx[p] = inside ? aw * (float)Wl * (fy0 * (d01 - d00) + fy1 * (d11 - d10)) : 0.f;
+        gy[p] = inside ? aw * (float)Hl * (fx0 * (d10 - d00) + fx1 * (d11 - d01)) : 0.f;
+      }
+      if (j == 0) {
+        *reinterpret_cast<float4*>(grad_w + pair * (NL * P) + l * P) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2) = make_float4(gx[0], gy[0], gx[1], gy[1]);
+        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2 + 4) = make_float4(gx[2], gy[2], gx[3], gy[3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- kernel B
+// Wave-per-query.  Lanes 0..NL*P-1 each work out ONE sampling point (pixel, four weights, flags); the
+// wave then walks the points with those values as scalars (v_readlane), and every atomic instruction
+// adds two contiguous 128-B rows: lanes 0-31 = the 32 channels of the left corner, lanes 32-63 = the
+// right corner.  No redundant coordinate arithmetic, at most 2-way LDS bank conflicts.
+template <int NL, int P>
+__global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
+    const float* __restrict__ loc, const float* __restrict__ attn_w, const float* __restrict__ grad_out,
+    float* __restrict__ grad_value, TileGeom g, int S, int Q, int heads, int n_logical, int per_xcd) {
+  constexpr int D = 32, kWaves = kBwdThreads / kWave, NP = NL * P;
+  static_assert(NP <= 64, "one lane per sampling point");
+  extern __shared__ __attribute__((aligned(16))) float4 win[];
+  float* winf = reinterpret_cast<float*>(win);
+  const int id = xcd_contiguous_id(blockIdx.x, per_xcd);
+  if (id >= n_logical) return;
+  int* lv_tab = reinterpret_cast<int*>(win + g.lv_tab_off4);
+  const TileCtx<NL> c = tile_setup<NL>(g, id, heads, lv_tab);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = lane & 31, hs = lane >> 5;  // channel, left / right corner
+  const int row_stride = heads * D;
+  float* gvb = grad_value + ((int64_t)c.b * S * heads + c.h) * D;
+
+  for (int i = tid; i < g.lv_tab_off4; i += kBwdThreads) win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  // this lane's point (lanes >= NP idle in the per-point phase): level constants
+  const int pl = lane < NP ? lane / P : 0;
+  int Wl_p = g.w[0], Hl_p = g.h[0], ww_p = g.win_w[0], wh_p = g.win_h[0], wx0_p = c.wx0[0], wy0_p = c.wy0[0];
+  int base_p = g.lds_off4[0] * 4, start_p = g.start[0];
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+    if (pl == l) {
+      Wl_p = g.w[l]; Hl_p = g.h[l]; ww_p = g.win_w[l]; wh_p = g.win_h[l]; wx0_p = c.wx0[l]; wy0_p = c.wy0[l];
+      base_p = g.lds_off4[l] * 4; start_p = g.start[l];
+    }
+
+  for (int qi = wave; qi < c.nq; qi += kWaves) {
+    const int q = tile_query<NL>(lv_tab, qi, Q);
+    const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
+    const float gof = grad_out[pair * D + ch];
+    // ---- per-point phase (one lane per point)
+    float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+    int lds_idx = -1, glb_idx = 0, flags = 0;  // flags: bit0..3 corner in image, bit4 footprint in window
+    if (lane < NP) {
+      const float2 lc = *reinterpret_cast<const float2*>(loc + pair * (NP * 2) + lane * 2);
+      const float aw = attn_w[pair * NP + lane];
+      float x, y;
+      pixel_coords(lc.x, lc.y, Wl_p, Hl_p, x, y);
+      if (x > -1.f && x < (float)Wl_p && y > -1.f && y < (float)Hl_p) {
+        const float x0f = floorf(x), y0f = floorf(y);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float fx1 = x - x0f, fy1 = y - y0f;
+        const float a1 = aw * fy1, a0 = aw - a1;
+        w01 = a0 * fx1; w00 = a0 - w01; w11 = a1 * fx1; w10 = a1 - w11;
+        const bool xl = x0 >= 0, xr = x0 + 1 < Wl_p, yt = y0 >= 0, yb = y0 + 1 < Hl_p;
+        flags = (yt && xl ? 1 : 0) | (yt && xr ? 2 : 0) | (yb && xl ? 4 : 0) | (yb && xr ? 8 : 0);
+        const int xrw = x0 - wx0_p, yrw = y0 - wy0_p;
+        if ((unsigned)xrw < (unsigned)(ww_p - 1) && (unsigned)yrw < (unsigned)(wh_p - 1)) {
+          flags |= 16;
+          lds_idx = base_p + (yrw * ww_p + xrw) * 32;  // float index of the top-left corner's row
+        }
+        glb_idx = (start_p + y0 * Wl_p + x0);  // token of the top-left corner (may be out of range: flags)
+        flags |= (ww_p << 8) | (Wl_p << 16);   // row pitches for the bottom corners (ww < 256, Wl < 65536)
+      }
+    }
+    // ---- per-corner-row phase: point parameters as wave-uniform scalars
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int f = __builtin_amdgcn_readlane(flags, p);
+      if ((f & 15) == 0) continue;  // point outside the image (uniform branch)
+      const float s00 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w00), p));
+      const float s01 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w01), p));
+      const float s10 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w10), p));
+      const float s11 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w11), p));
+      const int li = __builtin_amdgcn_readlane(lds_idx, p), gi = __builtin_amdgcn_readlane(glb_idx, p);
+      const int wwp = (f >> 8) & 0xff, Wlp = (f >> 16) & 0xffff;
+      const float wt = hs ? s01 : s00, wb = hs ? s11 : s10;
+      const bool ok_t = (f >> hs) & 1, ok_b = (f >> (2 + hs)) & 1;
+      if (f & 16) {  // whole footprint inside the window: LDS accumulation
+        if (ok_t) atomicAdd(winf + li + hs * 32 + ch, wt * gof);
+        if (ok_b) atomicAdd(winf + li + (wwp + hs) * 32 + ch, wb * gof);
+      } else {  // rare: straight to memory
+        if (ok_t) atomicAdd(gvb + (int64_t)(gi + hs) * row_stride + ch, wt * gof);
+        if (ok_b) atomicAdd(gvb + (int64_t)(gi + Wlp + hs) * row_stride + ch, wb * gof);
+      }
+    }
+  }
+  __syncthreads();
+  // flush: one lane per channel, 32 lanes per pixel -> every atomic wave-instruction is two whole 128-B rows
+  const int pslot = tid >> 5;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l];
+    const int npix = ww * g.win_h[l];
+    const float inv_ww = 1.f / (float)ww;
+    const float* wlf = winf + g.lds_off4[l] * 4;
+    float* glev = gvb + (int64_t)g.start[l] * row_stride;
+    for (int idx = pslot; idx < npix; idx += kBwdThreads / 32) {
+      const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
+      const int x = c.wx0[l] + wx, y = c.wy0[l] + wy;
+      if (x < 0 || x >= Wl || y < 0 || y >= Hl) continue;
+      const float v = wlf[idx * 32 + ch];
+      if (v != 0.f) atomicAdd(glev + (int64_t)(y * Wl + x) * row_stride + ch, v);
+    }
+  }
+}
+
+int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
+                     void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
+                     int margin, void* stream, const char* who, bool* handled) {
+  *handled = false;
+  if (P != 4 || L < 1 || L > kMaxLv || margin < 0 || (int64_t)Q != S) return WM2F_OK;
+  TiledPlan p = plan_tiled(level_hw, L, margin);
+  if (!p.ok) return WM2F_OK;
+  p.g.order = 1;
+  p.g.a_qstride = heads * L * P * 2;
+  p.g.b_qstride = heads * L * P;
+  const int64_t n_logical = (int64_t)B * heads * p.g.tiles_x * p.g.tiles_y;
+  if (n_logical > (1 << 30)) return WM2F_OK;
+  const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
+  hipStream_t st = (hipStream_t)stream;
+#define WM2F_TB(NLv)                                                                                              \
+  case NLv: {                                                                                                     \
+    auto ka = msdeform_tiled_bwd_lw_kernel<NLv, 4>;                                                               \
+    auto kb = msdeform_tiled_bwd_value_kernel<NLv, 4>;                                                            \
+    if (p.lds_bytes > 64 * 1024) {                                                                                \
+      hipError_t e1 = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
+      hipError_t e2 = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
+      if (e1 != hipSuccess || e2 != hipSuccess) {                                                                 \
+        set_error("%s: cannot raise dynamic LDS to %zu", who, p.lds_bytes);                                       \
+        return WM2F_ELAUNCH;                                                                                      \
+      }                                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL(ka, dim3(per_xcd* kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)value,       \
+                       (const float*)loc, (const float*)attn_w, (const float*)grad_out, (float*)grad_loc,         \
+                       (float*)grad_w, p.g, S, Q, heads, (int)n_logical, per_xcd);                                \
+    hipLaunchKernelGGL(kb, dim3(per_xcd* kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)loc,         \
+                       (const float*)attn_w, (const float*)grad_out, (float*)grad_value, p.g, S, Q, heads,        \
+                       (int)n_logical, per_xcd);                                                                  \
+  } break;
+  switch (L) {
+    WM2F_TB(1) WM2F_TB(2) WM2F_TB(3) WM2F_TB(4)
+    default: return WM2F_OK;
+  }
+#undef WM2F_TB
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: tiled backward launch failed: %s", who, hipGetErrorString(e));
+    return WM2F_ELAUNCH;
+  }
+  *handled = true;
+  return WM2F_OK;
+}
+
+}  // namespace wm2f

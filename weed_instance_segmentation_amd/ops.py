@@ -99,9 +99,9 @@ class _MSDeformAttn(torch.autograd.Function):
         g_w = torch.empty_like(attn_w)
         lv = host_i32([x for hw in ctx.level_hw for x in hw])
         with torch.cuda.device(value.device):
-            check(load().wm2f_msdeform_bwd(_p(value), _p(loc), _p(attn_w), _p(grad_out), _p(g_value), _p(g_loc),
-                                           _p(g_w), lv, B, S, Q, H, D, L, P, WM2F_F32, _stream(value)),
-                  "wm2f_msdeform_bwd")
+            check(_timed("msdeform_bwd", value, lambda: load().wm2f_msdeform_bwd(
+                _p(value), _p(loc), _p(attn_w), _p(grad_out), _p(g_value), _p(g_loc), _p(g_w), lv, B, S, Q, H, D, L, P,
+                WM2F_F32, _stream(value))), "wm2f_msdeform_bwd")
         return g_value, g_loc, g_w, None
 
 
