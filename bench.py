@@ -167,8 +167,12 @@ def main():
             n, us = ksum[k1_name]
             nbytes = 4 * (2 * B * Stok * H * D + B * Stok * H * L * P * 3)
             ach = nbytes / us / 1e3
+            traffic = None  # HBM bytes per launch from PMC counters of a separate rocprofv3 run (profiles/)
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_k1_traffic.json")
+            if B == 8 and S == 1024 and os.path.exists(tpath):
+                traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
             line["roofline"] = {"kernel": k1_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                 "algorithmic_bytes_per_launch": nbytes, "launches": n, "avg_us": round(us, 2)}
         if "mask_einsum_fwd" in ksum:
             n, us = ksum["mask_einsum_fwd"]
