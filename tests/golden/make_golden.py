@@ -342,6 +342,31 @@ def gen_full():
     save("full_tiny.npz", **arrays)
 
 
+def gen_swin():
+    """Swin backbone (transformers/models/swin/modeling_swin.py:1070-1150): feature maps of a reduced config,
+    on an input whose size is divisible by neither the patch nor the window (exercises every padding path)."""
+    from transformers import SwinConfig
+    from transformers.models.swin.modeling_swin import SwinBackbone
+    torch.manual_seed(21)
+    cfg = SwinConfig(embed_dim=16, depths=[1, 2, 2, 1], num_heads=[1, 2, 4, 4], window_size=4, mlp_ratio=2.0,
+                     out_features=["stage1", "stage2", "stage3", "stage4"])
+    m = SwinBackbone(cfg).eval()
+    randomise(m, 21)
+    g = torch.Generator().manual_seed(22)
+    arrays = {}
+    for tag, shape in (("a", (2, 3, 70, 98)), ("b", (1, 3, 64, 64))):
+        x = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            fm = m(x).feature_maps
+        arrays[f"x_{tag}"] = x
+        for i, f in enumerate(fm):
+            arrays[f"fm_{tag}_{i}"] = f
+    for k, v in m.state_dict().items():
+        arrays["sd." + k] = v
+    arrays["config_json"] = np.asarray(json.dumps(cfg.to_dict(), default=str))
+    save("swin_tiny_backbone.npz", **arrays)
+
+
 def gen_state_keys():
     from transformers import SwinConfig
     res = {}
@@ -361,8 +386,8 @@ def gen_state_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1", "a2", "k2", "k3", "k4", "full", "keys"]
+    which = sys.argv[1:] or ["k1", "a2", "k2", "k3", "k4", "full", "keys", "swin"]
     torch.set_num_threads(8)
     for w in which:
         {"k1": gen_k1, "a2": gen_a2, "k2": gen_k2, "k3": gen_k3, "k4": gen_k4, "full": gen_full,
-         "keys": gen_state_keys}[w]()
+         "keys": gen_state_keys, "swin": gen_swin}[w]()

@@ -100,3 +100,62 @@ def test_collate_fn_batch_contract():
     batch = dict(pixel_values=torch.stack([it["pixel_values"] for it in items]),
                  mask_labels=[it["mask_labels"] for it in items], class_labels=[it["class_labels"] for it in items])
     assert batch["pixel_values"].shape == (2, 3, 8, 8) and isinstance(batch["mask_labels"], list)
+
+
+def test_swin_backbone_matches_golden_and_names():
+    """The Swin backbone is stock torch ops, so its parity runs on CPU: feature maps vs the fixture made
+    from transformers' SwinBackbone (odd input sizes: every padding path), and the full Swin-T key set."""
+    import numpy as np
+    from conftest import load_golden
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    from weed_instance_segmentation_amd.backbone_swin import SwinBackbone
+    g = load_golden("swin_tiny_backbone.npz")
+    cfg = json.loads(str(g["config_json"]))
+    m = SwinBackbone(cfg).eval()
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)
+    for tag in ("a", "b"):
+        with torch.no_grad():
+            fm = m(torch.from_numpy(g[f"x_{tag}"]))
+        for i, f in enumerate(fm):
+            torch.testing.assert_close(f, torch.from_numpy(g[f"fm_{tag}_{i}"]), rtol=1e-4, atol=1e-4)
+    ks = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+    full = Mask2FormerForUniversalSegmentation(Mask2FormerConfig.from_dict(ks["swin_tiny_config"]))
+    own, exp = full.state_dict(), ks["swin_tiny_q100_l3"]
+    assert set(own) == set(exp) and all(list(own[k].shape) == exp[k] for k in exp)
+
+
+def test_legacy_swin_checkpoint_names_load(tmp_path):
+    """A transformers-4.x style checkpoint (attention.self.query ... and no `swin.` prefix) loads into the same tensors."""
+    from safetensors.torch import save_file
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    ks = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+    cd = dict(ks["swin_tiny_config"])
+    cd["backbone_config"] = dict(cd["backbone_config"], embed_dim=16, depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 4], window_size=4)
+    cd.update(feature_size=32, mask_feature_size=32, hidden_dim=32, num_attention_heads=2, encoder_layers=1,
+              decoder_layers=2, num_queries=5, dim_feedforward=32, encoder_feedforward_dim=32)
+    cfg = Mask2FormerConfig.from_dict(cd)
+    torch.manual_seed(0)
+    m = Mask2FormerForUniversalSegmentation(cfg)
+    pre = "model.pixel_level_module.encoder."
+    back = (("attention.q_proj", "attention.self.query"), ("attention.k_proj", "attention.self.key"),
+            ("attention.v_proj", "attention.self.value"),
+            ("attention.relative_position_bias.relative_position_bias_table", "attention.self.relative_position_bias_table"),
+            ("attention.o_proj", "attention.output.dense"), ("mlp.fc1", "intermediate.dense"), ("mlp.fc2", "output.dense"))
+    old = {}
+    for k, v in m.state_dict().items():
+        if k.startswith(pre + "swin.layernorm."):
+            continue
+        if k.startswith(pre + "swin."):
+            k = pre + k[len(pre) + 5:]
+            for a, b in back:
+                k = k.replace(a, b)
+        old[k] = v.detach().clone().contiguous()
+    assert any("attention.self.query" in k for k in old) and not any(".swin." in k for k in old)
+    cfg.save_pretrained(str(tmp_path))
+    save_file(old, os.path.join(str(tmp_path), "model.safetensors"))
+    m2 = Mask2FormerForUniversalSegmentation.from_pretrained(str(tmp_path))
+    a, b = m.state_dict(), m2.state_dict()
+    for k in a:
+        if ".swin.layernorm." not in k:
+            assert torch.equal(a[k], b[k]), k

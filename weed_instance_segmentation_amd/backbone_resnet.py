@@ -16,7 +16,7 @@ from . import ops
 
 def _fused_ok(x: torch.Tensor) -> bool:
     """Inference on the GPU with a float4-friendly map: use the fused bias(+residual)+ReLU pass."""
-    return (not torch.is_grad_enabled()) and x.dtype == torch.float32 and (x.shape[-1] * x.shape[-2]) % 4 == 0
+    return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and (x.shape[-1] * x.shape[-2]) % 4 == 0
 
 
 def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d, cache: dict):
@@ -164,4 +164,7 @@ def build_backbone(cfg: dict) -> nn.Module:
     mt = cfg.get("model_type")
     if mt == "resnet":
         return ResNetBackbone(cfg)
-    raise NotImplementedError(f"backbone model_type={mt!r} is not built yet (resnet only; Swin is planned)")
+    if mt == "swin":
+        from .backbone_swin import SwinBackbone
+        return SwinBackbone(cfg)
+    raise NotImplementedError(f"backbone model_type={mt!r} is not built (resnet and swin are)")

@@ -417,6 +417,36 @@ class Mask2FormerModel(nn.Module):
 
 
 # ------------------------------------------------------------------------------ top level
+_LEGACY_SWIN = (  # transformers 4.x checkpoint names -> 5.x (conversion_mapping.py:411-426 of 5.15.0), in order
+    ("attention.self.query", "attention.q_proj"), ("attention.self.key", "attention.k_proj"),
+    ("attention.self.value", "attention.v_proj"),
+    ("attention.self.relative_position_bias_table", "attention.relative_position_bias.relative_position_bias_table"),
+    ("attention.output.dense", "attention.o_proj"), ("intermediate.dense", "mlp.fc1"), ("output.dense", "mlp.fc2"))
+
+
+def _remap_legacy_backbone_keys(sd: dict, config) -> dict:
+    """Hub checkpoints written before transformers 5 (the reference's `facebook/mask2former-swin-large-coco-
+    instance`, config.py:4) name the Swin tensors differently; rename them the way the dependency does at load."""
+    bc = config.backbone_config if isinstance(config.backbone_config, dict) else {}
+    if bc.get("model_type") != "swin":
+        return sd
+    pre, out = "model.pixel_level_module.encoder.", {}
+    for k, v in sd.items():
+        if k.startswith(pre):
+            t = k[len(pre):]
+            if t.endswith("relative_position_index"):
+                continue  # recomputed buffer
+            for a, b in _LEGACY_SWIN:
+                t = t.replace(a, b)
+            if t.startswith("encoder.") or t.startswith("embeddings."):
+                t = "swin." + t
+            elif t.startswith("layernorm."):
+                t = "swin." + t
+            k = pre + t
+        out[k] = v
+    return out
+
+
 class Mask2FormerForUniversalSegmentation(nn.Module):
     """HF:2278-2530.  See the module docstring for the call contract."""
 
@@ -524,6 +554,7 @@ class Mask2FormerForUniversalSegmentation(nn.Module):
             sd = torch.load(bin_path, map_location="cpu", weights_only=True)
         else:
             raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {d}")
+        sd = _remap_legacy_backbone_keys(sd, config)
         own = model.state_dict()
         mismatched = [k for k, v in sd.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
         if mismatched and not ignore_mismatched_sizes:
@@ -531,7 +562,8 @@ class Mask2FormerForUniversalSegmentation(nn.Module):
         for k in mismatched:
             sd.pop(k)
         missing, unexpected = model.load_state_dict(sd, strict=False)
-        missing = [k for k in missing if k not in mismatched]
+        # the final Swin layernorm is unused by the backbone call and absent from pre-5.x checkpoints
+        missing = [k for k in missing if k not in mismatched and ".encoder.swin.layernorm." not in k]
         if missing or unexpected:
             raise RuntimeError(f"checkpoint does not match the module: missing={missing[:8]} unexpected={unexpected[:8]}")
         model.eval()
