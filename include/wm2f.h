@@ -87,10 +87,17 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
  *           62: LDS-window kernel with slab-major work order
  *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that
  *           from their reference point take a slow path (results never depend on it).
+ *           3 = phased quad kernel only (3 levels with sides 1:2:4 coarse first, P = 4, D = 32, margin 4);
+ *           13 / 23 / 43 / 73 = its timing ablations / stamped build.  Variant 0 tries 3, then 2, then 1.
  * wm2f_msdeform_fwd / _fused_fwd are variant 0, margin 4. */
 int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const void* ref, void* out,
                         const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
                         int dtype, int fused, int variant, int margin, void* stream);
+
+/* Profiling aid for K1: variant 73 of wm2f_msdeform_fwd_v is the phased quad kernel with in-kernel time stamps
+ * (s_memtime of wave 0, 16 slots per workgroup, first 8192 workgroups); this copies them to HOST memory
+ * (int64 [8192][16], n_bytes <= 1 MiB).  Synchronous; no reference counterpart. */
+int wm2f_debug_stamps(void* host_dst, int64_t n_bytes);
 
 /* ---- K3: mask einsum --------------------------------------------------------------------
  * Replaces torch.einsum("bqc,bchw->bqhw"), HF:2046.

@@ -114,6 +114,42 @@ def test_k1_tiled_local_offsets(ops, shapes, B, fused):
         torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shapes,B", [([(8, 8), (16, 16), (32, 32)], 2), ([(5, 7), (10, 14), (20, 28)], 3),
+                                      ([(1, 1), (2, 2), (4, 4)], 2), ([(3, 9), (6, 18), (12, 36)], 1),
+                                      ([(9, 5), (18, 10), (36, 20)], 2), ([(32, 32), (64, 64), (128, 128)], 1)])
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("spread", ["local", "wide"])
+def test_k1_quad_kernel(ops, shapes, B, fused, spread):
+    """Phased quad kernel (variant 3; what `auto` picks for the encoder's 1:2:4 pyramids): ragged edge tiles,
+    offsets inside the window margin (fast path) and far outside it (every point on the slow path)."""
+    H, D, L, P = 8, 32, 3, 4
+    g = torch.Generator().manual_seed(21)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * (2.0 if spread == "local" else 30.0)
+    off[0, S // 2, 1, 2, 3] = torch.tensor([-60.0, 45.0])
+    off[0, 0, 0, 0, 0] = torch.tensor([4.999, -4.999])  # the window's last column / first row
+    logits = torch.randn(B, S, H, L * P, generator=g) * 2
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    aw = torch.softmax(logits, -1).view(B, S, H, L, P)
+    ref = O.msdeform_attn_core(value, shapes, loc, aw)
+    if fused:
+        out = ops.ms_deform_attn_variant(dev(value), shapes, dev(off), dev(logits), dev(ref_pts), fused=True, variant=3)
+    else:
+        out = ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(aw), variant=3)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-5)  # fp32: 12-term sums of O(1) values
+
+
+def test_k1_quad_kernel_refuses_other_pyramids(ops):
+    from weed_instance_segmentation_amd._lib import Wm2fError
+    shapes = [(7, 9), (13, 17), (25, 33)]
+    value, loc, w = _rand_k1(1, shapes, 8, 32, 3)
+    with pytest.raises(Wm2fError):
+        ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(w), variant=3)
+
+
 @pytest.mark.parametrize("shapes,D", [([(8, 8), (16, 16), (32, 32)], 32), ([(5, 7), (10, 14), (20, 28)], 32),
                                       ([(4, 4), (8, 8), (16, 16)], 16)])
 def test_k1_fused_packed(ops, shapes, D):

@@ -1,0 +1,49 @@
+"""In-kernel timeline of the phased quad K1 kernel (variant 73 + wm2f_debug_stamps).
+
+Prints, per stamp interval, the median / p10 / p90 over workgroups in s_memtime ticks (100 MHz on gfx950:
+1 tick = 10 ns) and the workgroup's whole span."""
+import argparse, ctypes, json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from weed_instance_segmentation_amd import ops
+from weed_instance_segmentation_amd._lib import load, check
+
+NAMES = ["setup+operand loads issue", "DMA issue", "wait coarse(+operands)", "softmax/coords", "barrier0", "phase0 gather",
+         "wait mid", "barrier1", "phase1 gather", "wait fine", "barrier2", "phase2 gather", "slow+stores"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", type=int, default=73)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, H, D, L, P = 8, 8, 32, 3, 4
+    shapes = [(32, 32), (64, 64), (128, 128)]
+    S = sum(h * w for h, w in shapes)
+    torch.manual_seed(0)
+    value = torch.randn(B, S, H, D, device=dev)
+    off = torch.rand(B, S, H, L, P, 2, device=dev) * 8.0 - 4.0
+    logits = torch.randn(B, S, H, L * P, device=dev)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
+                     for h, w in shapes]).to(dev)
+    refl = ref[:, None, :].expand(S, L, 2).contiguous()
+    for _ in range(3):
+        ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
+    torch.cuda.synchronize()
+    n_wg = B * H * 64
+    buf = np.zeros((min(n_wg, 8192), 16), dtype=np.int64)
+    check(load().wm2f_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "wm2f_debug_stamps")
+    st = buf[:, :14].astype(np.float64)
+    d = np.diff(st, axis=1)
+    out = {"ticks": "s_memtime", "workgroups": int(st.shape[0])}
+    for i, n in enumerate(NAMES):
+        out[n] = [float(np.percentile(d[:, i], q)) for q in (10, 50, 90)]
+    span = st[:, 13] - st[:, 0]
+    out["span"] = [float(np.percentile(span, q)) for q in (10, 50, 90)]
+    out["kernel_ticks"] = float(st[:, 13].max() - st[:, 0].min())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="k1,k1f,k3,mask,k2,k4")
     ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--smooth", action="store_true", help="K1: slowly varying offsets instead of independent uniform ones")
     a = ap.parse_args()
     only = set(a.only.split(","))
     dev = torch.device("cuda:0")
@@ -39,13 +40,17 @@ def main():
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device="cpu").manual_seed(0)
     res = {}
-    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1b")):
+    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1b")):
         value = torch.randn(B, S, H, D, device=dev)
         # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
                          for h, w in shapes]).to(dev)  # (S,2) x,y
         # the module's initial pattern: |offset| <= 4 px (HF:2154-2166); uniform in [-4, 4]
         off = (torch.rand(B, S, H, L, P, 2, device=dev) * 8.0 - 4.0)
+        if a.smooth:  # a slowly varying offset field (what a Linear of neighbouring tokens' features gives) + small noise
+            pos = ref[None, :, None, None, None, :] * 6.283
+            ph = torch.rand(1, 1, H, L, P, 2, device=dev) * 6.283
+            off = 3.5 * torch.sin(pos * torch.tensor([1.0, 1.7], device=dev) + ph) + 0.1 * torch.randn(B, S, H, L, P, 2, device=dev)
         norm = torch.tensor([[w, h] for h, w in shapes], device=dev, dtype=torch.float32)
         loc = (ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
         logits = torch.randn(B, S, H, L * P, device=dev)
@@ -57,7 +62,7 @@ def main():
             res["k1_msdeform_fwd"] = r
         refl = ref[:, None, :].expand(S, L, 2).contiguous()
         if "k1v" in only:
-            for variant, margin in ((1, 4), (2, 4), (12, 4), (22, 4), (52, 4), (62, 4)):
+            for variant, margin in ((1, 4), (2, 4), (3, 4), (13, 4), (23, 4), (43, 4), (12, 4), (22, 4)):
                 r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, loc, aw, variant=variant, margin=margin), a.iters)
                 r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
                 res[f"k1_unfused_variant{variant}_margin{margin}"] = r
@@ -72,10 +77,11 @@ def main():
                 o.backward(go)
                 vv.grad = ll.grad = ww_.grad = None
             res["k1_fwd_plus_bwd"] = timeit(fb, a.iters)
-        if "k1t" in only:  # one variant only, for PMC runs
-            r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=2, margin=4), a.iters)
+        if "k1t" in only or "k1q" in only:  # one variant only, for PMC runs (k1t: LDS-window kernel, k1q: phased quad kernel)
+            vv_ = 2 if "k1t" in only else 3
+            r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=vv_, margin=4), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
-            res["k1_fused_variant2_margin4"] = r
+            res[f"k1_fused_variant{vv_}_margin4"] = r
         if "k1f" in only:
             r = timeit(lambda: ops.ms_deform_attn_fused(value, shapes, off, logits, refl), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)

@@ -27,6 +27,7 @@ SIGNATURES = {
     "wm2f_msdeform_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_debug_stamps": (c_int, [_P, c_int64]),
     "wm2f_mask_einsum_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_masked_xattn_workspace": (c_int64, [_I, _I, _I, _I, _I]),

@@ -243,6 +243,12 @@ int launch_tiled(const void* value, const void* a, const void* b, void* out, con
                  int Q, int heads, int L, int P, int margin, int threads, void* stream, const char* who,
                  bool* handled, int mode, int a_qstride, int b_qstride);
 
+// msdeform_quad.hip
+template <bool FUSED>
+int launch_quad(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S, int Q,
+                int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
+                int b_qstride);
+
 // msdeform_tiled_bwd.hip
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
                      void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
@@ -264,9 +270,9 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
   return g;
 }
 
-// variant: 0 = auto (LDS-window kernel when it applies, else direct gather), 1 = direct,
+// variant: 0 = auto (phased quad kernel, else LDS-window kernel, else direct gather), 1 = direct,
 //          2 = LDS-window kernel only; 12/22/32/42/52/62 = its timing ablations (invalid outputs
-//          except 62 = slab-major work order)
+//          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -277,6 +283,17 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   WM2F_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {8,16,32,64}", who, D);
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 3)) {
+    bool handled = false;
+    if (int rc = launch_quad<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
+                                    variant / 10, 0, 0))
+      return rc;
+    if (handled) return WM2F_OK;
+    if (variant != 0) {
+      set_error("%s: the phased quad kernel needs D=32, P=4, Q==S and 3 levels with sides 1:2:4, coarse first", who);
+      return WM2F_EUNSUPPORTED;
+    }
+  }
   if (variant != 1 && D == 32) {
     bool handled = false;
     if (int rc = launch_tiled<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, margin,
@@ -348,7 +365,13 @@ extern "C" int wm2f_msdeform_fused_packed_fwd(const void* value, const void* pac
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
   const int row = heads * L * P * 3;  // [offsets heads*L*P*2 | logits heads*L*P]
   bool handled = false;
-  if (D == 32) {
+  if (D == 32 && margin == 4) {
+    const float* a = (const float*)packed;
+    if (int rc = launch_quad<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, stream, who,
+                                   &handled, 0, row, row))
+      return rc;
+  }
+  if (D == 32 && !handled) {
     const float* a = (const float*)packed;
     if (int rc = launch_tiled<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, margin, 512,
                                     stream, who, &handled, 0, row, row))

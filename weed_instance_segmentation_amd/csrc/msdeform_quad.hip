@@ -1,0 +1,553 @@
+// K1, phased quad kernel: multi-scale deformable attention for the encoder's own shape
+// (3 levels ordered coarse -> fine with sides 1 : 2 : 4, 4 points, head_dim 32, queries == tokens).
+// Same arithmetic as msdeform.hip / msdeform_tiled.hip (transformers modeling_mask2former.py:798-837,
+// fused prologue :983-1002); this file changes WHO computes what and WHEN the windows arrive.
+//
+// What the LDS-window kernel (msdeform_tiled.hip) measured as its two limits, and the answer here:
+//  1. Instruction issue in the gather: with 4 lanes per query every lane repeated the whole
+//     coordinate / weight arithmetic of all 12 points (84 VALU per lane and point, 16 of them the
+//     FMAs).  Here lane j of a query's quad owns point j of every level: it computes that point's
+//     window address and four corner weights ONCE, and the quad shares them with DPP quad_perm
+//     broadcasts (v_mov_b32_dpp, 5 per point) -- about 37 VALU per lane and point.
+//  2. Staging and gather ran back to back (one 149.5-KiB workgroup per CU).  Here every thread
+//     keeps the accumulators of its (up to 3) queries in registers and the LEVELS are the phases:
+//     all three windows are requested up front by LDS-DMA with a fixed number of requests per
+//     wave, and the gather of the coarse level starts behind `s_waitcnt vmcnt(mid + fine)`, the
+//     mid level behind `vmcnt(fine)`: two thirds of the gather runs under the staging traffic.
+//     Each window is its own __shared__ array so that the compiler's LDS-DMA tracking (alias
+//     scopes) orders a window's ds_reads behind that window's requests only.
+//  Bank conflicts: a quad reads 64 contiguous bytes per ds_read_b128 and the four quads of a
+//  16-lane LDS group would all land on the same 16 banks (pixel stride 128 B); the quads alternate
+//  which 64-B half of the pixel they read first, so they spread over all four 16-bank blocks.
+//
+// Window geometry is compile-time: tile 16 x 16 finest-level pixels, margin 4 -> 14^2, 18^2, 26^2
+// pixels x 128 B = 25 + 41 + 85 KiB.
+// Points whose 2 x 2 footprint leaves the window take the slow path (global loads), as before.
+//
+// Roofline: HBM, algorithmic bytes as msdeform.hip (550 502 400 B per launch at config 2).
+#include "msdeform_tiled.h"
+
+namespace wm2f {
+
+namespace {
+
+constexpr int kQF = 16, kQM = 4;
+constexpr int kThreads = 512, kWavesQ = kThreads / kWave, kQuads = kThreads / 4, kPasses = 3;
+template <int LV> struct Win {
+  static constexpr int side = (kQF >> (2 - LV)) + 2 * kQM + 2;  // 14, 18, 26
+  static constexpr int npix = side * side;
+  static constexpr int chunks = (npix + 7) / 8;                 // 1-KiB LDS-DMA pieces: 25, 41, 85
+  static constexpr int per_wave = (chunks + kWavesQ - 1) / kWavesQ;  // requests per wave: 4, 6, 11
+};
+static_assert(Win<0>::per_wave == 4 && Win<1>::per_wave == 6 && Win<2>::per_wave == 11, "vmcnt constants below");
+
+struct QuadGeom {
+  int W0, H0;  // coarsest level; level l is (H0 << l, W0 << l)
+  int tiles_x, tiles_y;
+  int start[3];
+  int a_qstride, b_qstride;
+};
+
+__device__ const float4 g_zero_px[1] = {{0.f, 0.f, 0.f, 0.f}};
+
+// MODE 7 (variant 73): the kernel with in-kernel time stamps (s_memtime, wave 0 of each workgroup),
+// read back with wm2f_debug_stamps.  A profiling aid; no other mode touches this buffer.
+constexpr int kStampSlots = 16, kStampGroups = 8192;
+__device__ long long g_stamps[kStampGroups * kStampSlots];
+#define WM2F_STAMP(k)                                                                  \
+  do {                                                                                 \
+    if (MODE == 7 && tid == 0 && id < kStampGroups) g_stamps[id * kStampSlots + (k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+
+template <int K>
+__device__ __forceinline__ float bcast(float v) {  // value of lane K of this lane's quad
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xF, 0xF, true));
+}
+template <int K>
+__device__ __forceinline__ int bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+  return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+constexpr int waitcnt_vm(int n) { return (n & 15) | (0x7 << 4) | (0xF << 8) | ((n >> 4) << 14); }  // vmcnt(n) only
+
+// s_waitcnt vmcnt(N) that survives the compiler's own wait insertion.  While an LDS-DMA is pending,
+// SIInsertWaitcnts answers ANY vmcnt need of the next instruction with vmcnt(0) (it treats the DMA
+// as a flat access that may complete out of order) and folds that into a directly preceding wait.
+// The s_nop needs nothing, so the counted wait is emitted as written and entered in the pass's
+// scoreboard; the loads it covers are then known complete when their first user follows.
+// Workgroup barrier without the memory-model fence of __syncthreads(): the fence makes the compiler
+// drain vmcnt while LDS-DMA is pending.  What the fence would order is ordered here by hand: a
+// window is read only behind the counted wait of every wave (wait_vm) plus this barrier, and the
+// "memory" clobbers keep the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(waitcnt_vm(N));
+  asm volatile("s_nop 0");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+struct Acc {
+  f32x2 a_lo, a_hi, b_lo, b_hi;  // first-read half (4 channels), second-read half
+};
+
+// Request one level's window: a wave-instruction moves 8 pixels x 128 B, lane-linear in LDS.
+// EVERY wave issues exactly Win<LV>::per_wave requests, so that the phase waits can count them; the
+// few requests beyond the last piece fetch that last piece again (same bytes to the same place).
+// (A separate landing pad for them would be cheaper on the memory side, but a conditional LDS-DMA
+// into a second LDS object makes the compiler's LDS-DMA tracking give up and drain vmcnt to 0
+// before the first window read -- measured on the ISA.)
+// Addressing: buffer_load_dwordx4 ... lds through a descriptor of this (image, head, level) slab and a
+// 32-bit byte offset per lane; a pixel outside the image gets an offset that fails the descriptor's
+// range check, and the hardware then writes zeros to LDS (tools/probes/lds_dma_oob.hip) = zero padding.
+constexpr unsigned kOobOffset = 0x80000000u;
+
+template <int LV>
+__device__ __forceinline__ void stage_level(float4* win, __amdgpu_buffer_rsrc_t slab, int Wl, int Hl, int wx0, int wy0,
+                                            int row_bytes, int wave, unsigned pix_lane, unsigned lane_part) {
+  using W = Win<LV>;
+#pragma unroll
+  for (int i = 0; i < W::per_wave; ++i) {
+    int c = wave + kWavesQ * i;
+    c = c < W::chunks ? c : W::chunks - 1;
+    const unsigned idx = (unsigned)(c * 8) + pix_lane;  // < 1024; the tail of the last piece lands in its padding
+    const unsigned wy = idx / (unsigned)W::side, wx = idx - wy * (unsigned)W::side;
+    const int x = wx0 + (int)wx, y = wy0 + (int)wy;
+    const bool in = ((unsigned)x < (unsigned)Wl) & ((unsigned)y < (unsigned)Hl);
+    const unsigned off = in ? __umul24(__umul24((unsigned)y, (unsigned)Wl) + (unsigned)x, (unsigned)row_bytes) + lane_part
+                            : kOobOffset;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, 0);
+  }
+}
+
+// What a lane publishes to its quad for one (query, level): its point's top-left corner (byte offset
+// in the window) and the four corner weights, attention weight folded in; zeros when the point is
+// not inside the window (slow path) or the query slot is empty.
+struct Prod {
+  int addr;
+  float w00, w01, w10, w11;
+};
+
+template <int LV>
+__device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, int wy0, bool valid, unsigned& slow) {
+  constexpr int WW = Win<LV>::side;
+  const float x0f = floorf(px), y0f = floorf(py);
+  const int xr = (int)x0f - wx0, yr = (int)y0f - wy0;
+  const bool fast = ((unsigned)xr < (unsigned)(WW - 1)) & ((unsigned)yr < (unsigned)(WW - 1));
+  const bool use = fast & valid;
+  Prod p;
+  p.addr = use ? (yr * WW + xr) * 128 : 0;
+  const float a = use ? aw : 0.f;
+  slow |= (valid & !fast) ? (1u << LV) : 0u;
+  const float fx1 = px - x0f, fy1 = py - y0f;
+  const float a1 = a * fy1, a0 = a - a1;
+  p.w01 = a0 * fx1;
+  p.w00 = a0 - p.w01;
+  p.w11 = a1 * fx1;
+  p.w10 = a1 - p.w11;
+  return p;
+}
+
+struct Group {  // the 8 corner reads of one point (2 halves x 4 corners) and its 4 weights
+  float4 v[8];
+  float q[4];
+};
+
+template <int LV, int K, int MODE>
+__device__ __forceinline__ void read_group(const float4* win, const Prod& p, int off1, int off2, Group& gr) {
+  constexpr int WW = Win<LV>::side;
+  const int ak = bcast<K>(p.addr);
+  gr.q[0] = bcast<K>(p.w00);
+  gr.q[1] = bcast<K>(p.w01);
+  gr.q[2] = bcast<K>(p.w10);
+  gr.q[3] = bcast<K>(p.w11);
+  const char* base = reinterpret_cast<const char*>(win);
+  const float4* c1 = reinterpret_cast<const float4*>(base + ak + off1);
+  const float4* c2 = reinterpret_cast<const float4*>(base + ak + off2);
+  if (MODE == 4) {  // ablation: no LDS reads
+    const float4 z = make_float4(gr.q[0], gr.q[1], gr.q[2], gr.q[3]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gr.v[i] = z;
+    asm volatile("" ::"v"(c1), "v"(c2));
+    return;
+  }
+  gr.v[0] = c1[0];
+  gr.v[1] = c1[8];
+  gr.v[2] = c1[WW * 8];
+  gr.v[3] = c1[WW * 8 + 8];
+  gr.v[4] = c2[0];
+  gr.v[5] = c2[8];
+  gr.v[6] = c2[WW * 8];
+  gr.v[7] = c2[WW * 8 + 8];
+}
+
+__device__ __forceinline__ void fma_group(Acc& acc, const Group& gr) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pk_fma4(acc.a_lo, acc.a_hi, gr.q[i], gr.v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pk_fma4(acc.b_lo, acc.b_hi, gr.q[i], gr.v[4 + i]);
+  // Pin the sums here: the accumulators are only stored under `if (valid)` at the very end, and
+  // LLVM's code sinking otherwise moves whole FMA chains down there (every corner then stays live
+  // across all three phases: 500+ spills).
+  asm volatile("" : "+v"(acc.a_lo), "+v"(acc.a_hi), "+v"(acc.b_lo), "+v"(acc.b_hi));
+}
+
+// One level for all kPasses queries of the lane: 12 groups (pass t, producer lane k) in a software
+// pipeline -- the reads of group i + 1 are issued before the FMAs of group i.
+template <int LV, int GI, int MODE>
+__device__ __forceinline__ void pipe_step(const float4* win, Acc (&acc)[kPasses], const Prod (&pr)[kPasses], int off1,
+                                          int off2, Group (&gr)[2], bool skip_last) {
+  if constexpr (GI < kPasses * 4) {
+    if (GI == (kPasses - 1) * 4 && skip_last) return;  // wave-uniform: the last pass holds no query in this wave
+    if constexpr (GI + 1 < kPasses * 4) read_group<LV, (GI + 1) & 3, MODE>(win, pr[(GI + 1) >> 2], off1, off2, gr[(GI + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_group(acc[GI >> 2], gr[GI & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_step<LV, GI + 1, MODE>(win, acc, pr, off1, off2, gr, skip_last);
+  }
+}
+
+template <int LV, int MODE>
+__device__ __forceinline__ void gather_phase(const float4* win, Acc (&acc)[kPasses], const float (&px)[kPasses][3],
+                                             const float (&py)[kPasses][3], const float (&wt)[kPasses][3],
+                                             const bool (&valid)[kPasses], int wx0, int wy0, unsigned (&slow)[kPasses],
+                                             int off1, int off2, bool skip_last) {
+  Prod pr[kPasses];
+#pragma unroll
+  for (int t = 0; t < kPasses; ++t) pr[t] = produce<LV>(px[t][LV], py[t][LV], wt[t][LV], wx0, wy0, valid[t], slow[t]);
+  Group gr[2];
+  read_group<LV, 0, MODE>(win, pr[0], off1, off2, gr[0]);
+  pipe_step<LV, 0, MODE>(win, acc, pr, off1, off2, gr, skip_last);
+}
+
+// Slow path for one point and 4 channels: per-corner image-bounds checks, corners from global memory.
+__device__ __forceinline__ void quad_point_slow(float4& acc, const float* __restrict__ vlev, int Hl, int Wl,
+                                                int row_stride, float x, float y, float aw) {
+  if (!(x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl)) return;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+  const bool xl = x0 >= 0, xr = x0 + 1 < Wl, yt = y0 >= 0, yb = y0 + 1 < Hl;
+  const float* p00 = vlev + (int64_t)(y0 * Wl + x0) * row_stride;
+  if (yt && xl) fma4s(acc, aw * fy0 * fx0, ld4g(p00));
+  if (yt && xr) fma4s(acc, aw * fy0 * fx1, ld4g(p00 + row_stride));
+  if (yb && xl) fma4s(acc, aw * fy1 * fx0, ld4g(p00 + (int64_t)Wl * row_stride));
+  if (yb && xr) fma4s(acc, aw * fy1 * fx1, ld4g(p00 + (int64_t)(Wl + 1) * row_stride));
+}
+
+// FUSED = false: a = loc (B,Q,heads,3,4,2), b = attn_w (B,Q,heads,3,4)
+// FUSED = true : a = raw offsets, b = raw logits; reference points are recomputed from the query grid.
+// MODE 0 = the kernel; 1 = staging only, 2 = gather only, 4 = gather without LDS reads: timing
+// ablations (outputs NOT valid), reachable only through wm2f_msdeform_fwd_v variants 13 / 23 / 43.
+template <bool FUSED, int MODE>
+__global__ __launch_bounds__(kThreads) void msdeform_quad_fwd_kernel(const float* __restrict__ value,
+                                                                     const float* __restrict__ a_in,
+                                                                     const float* __restrict__ b_in,
+                                                                     float* __restrict__ out, QuadGeom g, int S, int Q,
+                                                                     int heads, int n_logical, int per_xcd) {
+  constexpr int D = 32, NL = 3, P = 4;
+  __shared__ __attribute__((aligned(16))) float4 win0[Win<0>::chunks * 64];
+  __shared__ __attribute__((aligned(16))) float4 win1[Win<1>::chunks * 64];
+  __shared__ __attribute__((aligned(16))) float4 win2[Win<2>::chunks * 64];
+  const int id = xcd_contiguous_id(blockIdx.x, per_xcd);
+  if (id >= n_logical) return;
+  const int n_tiles = g.tiles_x * g.tiles_y;
+  const int h = id % heads, bt = id / heads;  // heads innermost: the 8 heads of a tile share loc / weight lines
+  const int tile = bt % n_tiles, b = bt / n_tiles;
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  const int tid = threadIdx.x, j = tid & 3;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Quad -> query and first-read half, chosen for the LDS banks.  A ds_read_b128 is served in 16-lane groups
+  // {0-3,12-15,20-27} / {4-11,16-19,28-31}: quads {0,3,5,6} / {1,2,4,7} of each half-wave.  A quad reads 64 B =
+  // one of four 16-bank blocks: block = 2 * (pixel & 1) + half.  Group mates that read the same half get
+  // NEIGHBOURING queries of a tile row: for an offset field that varies slowly they sample the same pixel
+  // (same address: broadcast) or adjacent pixels (other parity), the other pair reads the other half first,
+  // so the four quads of a group fall in four different blocks.  (Independent random offsets still collide:
+  // 1.75 LDS cycles per group on average, measured 1.71.)
+  const int quad = lane >> 2;
+  const int xq = (0x73261540 >> ((quad & 7) * 4)) & 7;      // quads 0..7 -> row positions 0,4,5,1,6,2,3,7
+  const int slot = (tid >> 6) * 16 + (quad & 8) + xq;
+  const int hq = (quad >> 2) & 1;                            // which 64-B half of a pixel this quad reads first
+  const int off1 = j * 16 + hq * 64, off2 = j * 16 + (1 - hq) * 64;
+  const int row_stride = heads * D;
+  const float* vb = value + ((int64_t)b * S * heads + h) * D;  // head slice of token 0
+  WM2F_STAMP(0);
+
+  // ---- per-level geometry of this tile (wave-uniform).  Level l has sides (H0 << l, W0 << l).
+  int wx0[NL], wy0[NL], qx0[NL], qy0[NL], nqx[NL], qcnt[NL + 1];
+  qcnt[0] = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
+    qx0[l] = tx * fq;
+    qy0[l] = ty * fq;
+    wx0[l] = qx0[l] - 1 - kQM;  // floor(first pixel coordinate - 0.5) - margin
+    wy0[l] = qy0[l] - 1 - kQM;
+    int nx = Wl - qx0[l], ny = Hl - qy0[l];
+    nx = nx < 0 ? 0 : (nx > fq ? fq : nx);
+    ny = ny < 0 ? 0 : (ny > fq ? fq : ny);
+    nqx[l] = nx;
+    qcnt[l + 1] = qcnt[l] + nx * ny;
+  }
+  const int nq = qcnt[NL];
+
+  // ---- this lane's operands: point j of every level, for up to kPasses queries (32-bit buffer offsets)
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_in, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_in, 0, 0x7fffffff, 0x00020000);
+  float2 lc[kPasses][NL];
+  float wt[kPasses][NL];
+  float refx[kPasses], refy[kPasses];
+  int qrow[kPasses];  // b * Q + q
+  bool valid[kPasses];
+  const float inv_w0 = __builtin_amdgcn_rcpf((float)g.W0), inv_h0 = __builtin_amdgcn_rcpf((float)g.H0);
+#pragma unroll
+  for (int t = 0; t < kPasses; ++t) {
+    int qi = slot + kQuads * t;
+    valid[t] = qi < nq;
+    if (!valid[t]) qi = 0;
+    const bool ge1 = qi >= qcnt[1], ge2 = qi >= qcnt[2];
+    const int lq = (ge1 ? 1 : 0) + (ge2 ? 1 : 0);
+    const int nx = ge2 ? nqx[2] : (ge1 ? nqx[1] : nqx[0]);
+    const int ox = ge2 ? qx0[2] : (ge1 ? qx0[1] : qx0[0]);
+    const int oy = ge2 ? qy0[2] : (ge1 ? qy0[1] : qy0[0]);
+    const int loc_i = qi - (ge2 ? qcnt[2] : (ge1 ? qcnt[1] : 0));
+    const int nxs = nx < 1 ? 1 : nx;
+    const int ly_ = (int)(((float)loc_i + 0.5f) * __builtin_amdgcn_rcpf((float)nxs));  // exact: small integers
+    const int lx_ = loc_i - ly_ * nxs;
+    const int qxi = ox + lx_, qyi = oy + ly_;
+    int q = (ge2 ? g.start[2] : (ge1 ? g.start[1] : 0)) + (int)__umul24((unsigned)qyi, (unsigned)(g.W0 << lq)) + qxi;
+    if (q > Q - 1) q = Q - 1;
+    qrow[t] = b * Q + q;
+    // (q + 0.5) / (W0 * 2^lq): the power of two is exact, so this equals (q + 0.5) * rcp(W_q)
+    const float sc = ge2 ? 0.25f : (ge1 ? 0.5f : 1.f);
+    refx[t] = ((float)qxi + 0.5f) * (inv_w0 * sc);
+    refy[t] = ((float)qyi + 0.5f) * (inv_h0 * sc);
+    const int a_off = (qrow[t] * g.a_qstride + h * (NL * P * 2) + j * 2) * 4;
+    const int b_off = (qrow[t] * g.b_qstride + h * (NL * P) + j) * 4;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      lc[t][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, 0));
+      wt[t][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, 0));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // the vmcnt constants below rely on this order: operands, coarse, mid, fine
+  WM2F_STAMP(1);
+
+  // ---- 1. request all three windows (4 + 6 + 11 LDS-DMA instructions per wave)
+  if (MODE != 2) {
+    const unsigned pix_lane = (unsigned)lane >> 3, lane_part = ((unsigned)lane & 7u) * 16u;
+    const int row_bytes = row_stride * 4, px0 = g.W0 * g.H0;
+    // one descriptor per level: this (image, head)'s slab from the level's first token to its last pixel
+    const __amdgpu_buffer_rsrc_t s0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vb + (int64_t)g.start[0] * row_stride), 0, (px0 - 1) * row_bytes + D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t s1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vb + (int64_t)g.start[1] * row_stride), 0, (4 * px0 - 1) * row_bytes + D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t s2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(vb + (int64_t)g.start[2] * row_stride), 0, (16 * px0 - 1) * row_bytes + D * 4, 0x00020000);
+    stage_level<0>(win0, s0, g.W0, g.H0, wx0[0], wy0[0], row_bytes, wave, pix_lane, lane_part);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_level<1>(win1, s1, g.W0 << 1, g.H0 << 1, wx0[1], wy0[1], row_bytes, wave, pix_lane, lane_part);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_level<2>(win2, s2, g.W0 << 2, g.H0 << 2, wx0[2], wy0[2], row_bytes, wave, pix_lane, lane_part);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  WM2F_STAMP(2);
+  if (MODE == 1) {  // ablation: staging only
+    wait_vm<0>();
+    wg_barrier();
+    if (tid == 0) out[(int64_t)id] = win0[id & 1023].x + win1[id & 1023].y + win2[id & 1023].z + lc[0][0].x + wt[2][2];
+    return;
+  }
+
+  // ---- 2. operands + coarse window of THIS wave have landed; mid and fine stay in flight
+  if (MODE != 2) wait_vm<Win<1>::per_wave + Win<2>::per_wave>();
+  WM2F_STAMP(3);
+  // per-point pixel coordinates and (fused) softmax weights, while the other waves' requests land
+  float px[kPasses][NL], py[kPasses][NL], sm_max[kPasses], sm_inv[kPasses];
+#pragma unroll
+  for (int t = 0; t < kPasses; ++t) {
+    sm_max[t] = 0.f;
+    sm_inv[t] = 1.f;
+    if (FUSED) {  // softmax over the 12 logits of the quad (HF:986-991)
+      const float mx = quad_max(fmaxf(fmaxf(wt[t][0], wt[t][1]), wt[t][2]));
+      float s = 0.f;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        wt[t][l] = __expf(wt[t][l] - mx);
+        s += wt[t][l];
+      }
+      const float inv = __builtin_amdgcn_rcpf(quad_sum(s));
+#pragma unroll
+      for (int l = 0; l < NL; ++l) wt[t][l] *= inv;
+      sm_max[t] = mx;
+      sm_inv[t] = inv;
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const float Wl = (float)(g.W0 << l), Hl = (float)(g.H0 << l);
+      if (FUSED) {  // loc = ref + off / (W, H); pixel = loc * (W, H) - 0.5  ==  ref * W - 0.5 + off
+        px[t][l] = (refx[t] * Wl - 0.5f) + lc[t][l].x;
+        py[t][l] = (refy[t] * Hl - 0.5f) + lc[t][l].y;
+      } else {  // grid_sample's own arithmetic (align_corners = False)
+        px[t][l] = ((2.f * lc[t][l].x - 1.f + 1.f) * Wl - 1.f) * 0.5f;
+        py[t][l] = ((2.f * lc[t][l].y - 1.f + 1.f) * Hl - 1.f) * 0.5f;
+      }
+    }
+  }
+  Acc acc[kPasses];
+  unsigned slow[kPasses];
+#pragma unroll
+  for (int t = 0; t < kPasses; ++t) {
+    acc[t].a_lo = acc[t].a_hi = acc[t].b_lo = acc[t].b_hi = (f32x2){0.f, 0.f};
+    slow[t] = 0;
+  }
+
+  // wave-uniform: no lane of this wave holds a query in the last pass (waves 5-7 of an interior tile)
+  const bool skip_last = __builtin_amdgcn_ballot_w64(valid[kPasses - 1]) == 0;
+  __builtin_amdgcn_sched_barrier(0);
+  WM2F_STAMP(4);
+  wg_barrier();  // every wave's coarse requests have landed
+  WM2F_STAMP(5);
+  gather_phase<0, MODE>(win0, acc, px, py, wt, valid, wx0[0], wy0[0], slow, off1, off2, skip_last);
+  WM2F_STAMP(6);
+
+  if (MODE != 2) wait_vm<Win<2>::per_wave>();
+  WM2F_STAMP(7);
+  wg_barrier();
+  WM2F_STAMP(8);
+  gather_phase<1, MODE>(win1, acc, px, py, wt, valid, wx0[1], wy0[1], slow, off1, off2, skip_last);
+  WM2F_STAMP(9);
+
+  if (MODE != 2) wait_vm<0>();
+  WM2F_STAMP(10);
+  wg_barrier();
+  WM2F_STAMP(11);
+  gather_phase<2, MODE>(win2, acc, px, py, wt, valid, wx0[2], wy0[2], slow, off1, off2, skip_last);
+  WM2F_STAMP(12);
+
+  // ---- 3. slow points (rare), then the stores
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
+  const bool any_slow = (slow[0] | slow[1] | slow[2]) != 0;
+  const bool wave_slow = __builtin_amdgcn_ballot_w64(any_slow) != 0;
+#pragma unroll
+  for (int t = 0; t < kPasses; ++t) {
+    if (!valid[t]) continue;
+    float4 r1 = make_float4(acc[t].a_lo.x, acc[t].a_lo.y, acc[t].a_hi.x, acc[t].a_hi.y);
+    float4 r2 = make_float4(acc[t].b_lo.x, acc[t].b_lo.y, acc[t].b_hi.x, acc[t].b_hi.y);
+    if (wave_slow) {
+      const unsigned bits = (unsigned)bcast<0>((int)slow[t]) | ((unsigned)bcast<1>((int)slow[t]) << 3) |
+                            ((unsigned)bcast<2>((int)slow[t]) << 6) | ((unsigned)bcast<3>((int)slow[t]) << 9);
+      unsigned todo = bits;  // bit (k * 3 + l): point k of level l
+      const float* ap = a_in + (int64_t)qrow[t] * g.a_qstride + h * (NL * P * 2);
+      const float* bp = b_in + (int64_t)qrow[t] * g.b_qstride + h * (NL * P);
+      while (todo) {
+        const int i = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const int k = i / 3, l = i - k * 3;
+        const int Wl = g.W0 << l, Hl = g.H0 << l;
+        const int st_l = l == 0 ? g.start[0] : (l == 1 ? g.start[1] : g.start[2]);
+        const float lx = ap[(l * P + k) * 2], ly = ap[(l * P + k) * 2 + 1];
+        float aw = bp[l * P + k], x, y;
+        if (FUSED) {
+          aw = __expf(aw - sm_max[t]) * sm_inv[t];
+          x = (refx[t] * (float)Wl - 0.5f) + lx;
+          y = (refy[t] * (float)Hl - 0.5f) + ly;
+        } else {
+          x = ((2.f * lx - 1.f + 1.f) * (float)Wl - 1.f) * 0.5f;
+          y = ((2.f * ly - 1.f + 1.f) * (float)Hl - 1.f) * 0.5f;
+        }
+        const float* vlev = vb + (int64_t)st_l * row_stride;
+        quad_point_slow(r1, vlev + (off1 >> 2), Hl, Wl, row_stride, x, y, aw);
+        quad_point_slow(r2, vlev + (off2 >> 2), Hl, Wl, row_stride, x, y, aw);
+      }
+    }
+    const int o_off = (qrow[t] * heads + h) * (D * 4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, o_off + off1, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, o_off + off2, 0, 0);
+  }
+  WM2F_STAMP(13);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ host side
+// Applies when: 3 levels ordered coarse -> fine with sides exactly 1 : 2 : 4, 4 points, queries == tokens.
+template <bool FUSED>
+int launch_quad(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S, int Q,
+                int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
+                int b_qstride) {
+  *handled = false;
+  if (P != 4 || L != 3 || (int64_t)Q != S) return WM2F_OK;
+  const int H0 = level_hw[0], W0 = level_hw[1];
+  for (int l = 1; l < 3; ++l)
+    if (level_hw[2 * l] != (H0 << l) || level_hw[2 * l + 1] != (W0 << l)) return WM2F_OK;
+  if (H0 < 1 || W0 < 1 || (int64_t)H0 * W0 * 21 != S) return WM2F_OK;
+  QuadGeom g;
+  g.W0 = W0;
+  g.H0 = H0;
+  g.tiles_x = (4 * W0 + kQF - 1) / kQF;
+  g.tiles_y = (4 * H0 + kQF - 1) / kQF;
+  g.start[0] = 0;
+  g.start[1] = H0 * W0;
+  g.start[2] = 5 * H0 * W0;
+  g.a_qstride = a_qstride > 0 ? a_qstride : heads * L * P * 2;
+  g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
+  const int64_t n_logical = (int64_t)B * heads * g.tiles_x * g.tiles_y;
+  if (n_logical > (1 << 30)) return WM2F_OK;
+  // 32-bit byte offsets into loc / weights / out, 24-bit multiplies in the window addressing
+  const int64_t lim = 0x7fffffff;
+  if ((int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
+      (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)16 * H0 * W0 >= (1 << 24) || heads * 32 * 4 >= (1 << 24))
+    return WM2F_OK;
+  const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
+  auto kfn = msdeform_quad_fwd_kernel<FUSED, 0>;
+  if (mode == 1) kfn = msdeform_quad_fwd_kernel<FUSED, 1>;
+  if (mode == 2) kfn = msdeform_quad_fwd_kernel<FUSED, 2>;
+  if (mode == 4) kfn = msdeform_quad_fwd_kernel<FUSED, 4>;
+  if (mode == 7) kfn = msdeform_quad_fwd_kernel<FUSED, 7>;
+  hipLaunchKernelGGL(kfn, dim3(per_xcd * kNumXcd), dim3(kThreads), 0, (hipStream_t)stream, (const float*)value,
+                     (const float*)a, (const float*)b, (float*)out, g, S, Q, heads, (int)n_logical, per_xcd);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: quad launch failed: %s", who, hipGetErrorString(e));
+    return WM2F_ELAUNCH;
+  }
+  *handled = true;
+  return WM2F_OK;
+}
+
+template int launch_quad<false>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
+                                int, void*, const char*, bool*, int, int, int);
+template int launch_quad<true>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
+                               int, void*, const char*, bool*, int, int, int);
+
+}  // namespace wm2f
+
+// Copy the MODE-7 time stamps (int64 [8192 workgroups][16 slots], s_memtime ticks) to host memory.
+extern "C" int wm2f_debug_stamps(void* host_dst, int64_t n_bytes) {
+  using namespace wm2f;
+  WM2F_REQUIRE(host_dst && n_bytes > 0 && n_bytes <= (int64_t)sizeof(long long) * kStampGroups * kStampSlots,
+               "wm2f_debug_stamps: bad destination / size");
+  hipError_t e = hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)n_bytes, 0, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    set_error("wm2f_debug_stamps: %s", hipGetErrorString(e));
+    return WM2F_ELAUNCH;
+  }
+  return WM2F_OK;
+}
