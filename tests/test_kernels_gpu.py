@@ -116,11 +116,14 @@ def test_k1_tiled_local_offsets(ops, shapes, B, fused):
 
 @pytest.mark.parametrize("shapes,B", [([(8, 8), (16, 16), (32, 32)], 2), ([(5, 7), (10, 14), (20, 28)], 3),
                                       ([(1, 1), (2, 2), (4, 4)], 2), ([(3, 9), (6, 18), (12, 36)], 1),
-                                      ([(9, 5), (18, 10), (36, 20)], 2), ([(32, 32), (64, 64), (128, 128)], 1)])
+                                      ([(9, 5), (18, 10), (36, 20)], 2), ([(32, 32), (64, 64), (128, 128)], 1),
+                                      ([(32, 32), (64, 64), (128, 128)], 6)])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("spread", ["local", "wide"])
-def test_k1_quad_kernel(ops, shapes, B, fused, spread):
-    """Phased quad kernel (variant 3; what `auto` picks for the encoder's 1:2:4 pyramids): ragged edge tiles,
+@pytest.mark.parametrize("variant", [3, 4])
+def test_k1_quad_kernel(ops, shapes, B, fused, spread, variant):
+    """Phased quad kernel (variant 3) and its streaming form (variant 4: persistent workgroups + loader waves; what
+    `auto` picks for the encoder's 1:2:4 pyramids): ragged edge tiles, several tiles per workgroup,
     offsets inside the window margin (fast path) and far outside it (every point on the slow path)."""
     H, D, L, P = 8, 32, 3, 4
     g = torch.Generator().manual_seed(21)
@@ -136,9 +139,9 @@ def test_k1_quad_kernel(ops, shapes, B, fused, spread):
     aw = torch.softmax(logits, -1).view(B, S, H, L, P)
     ref = O.msdeform_attn_core(value, shapes, loc, aw)
     if fused:
-        out = ops.ms_deform_attn_variant(dev(value), shapes, dev(off), dev(logits), dev(ref_pts), fused=True, variant=3)
+        out = ops.ms_deform_attn_variant(dev(value), shapes, dev(off), dev(logits), dev(ref_pts), fused=True, variant=variant)
     else:
-        out = ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(aw), variant=3)
+        out = ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(aw), variant=variant)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-5)  # fp32: 12-term sums of O(1) values
 
 

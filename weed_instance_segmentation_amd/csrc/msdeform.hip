@@ -249,6 +249,11 @@ int launch_quad(const void* value, const void* a, const void* b, void* out, cons
                 int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
                 int b_qstride);
 
+template <bool FUSED>
+int launch_stream(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
+                  int Q, int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
+                  int b_qstride);
+
 // msdeform_tiled_bwd.hip
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
                      void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
@@ -272,7 +277,8 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
 
 // variant: 0 = auto (phased quad kernel, else LDS-window kernel, else direct gather), 1 = direct,
 //          2 = LDS-window kernel only; 12/22/32/42/52/62 = its timing ablations (invalid outputs
-//          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations
+//          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations;
+//          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -283,6 +289,17 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   WM2F_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {8,16,32,64}", who, D);
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4)) {
+    bool handled = false;
+    if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
+                                      variant / 10, 0, 0))
+      return rc;
+    if (handled) return WM2F_OK;
+    if (variant != 0) {
+      set_error("%s: the streaming quad kernel needs D=32, P=4, Q==S and 3 levels with sides 1:2:4, coarse first", who);
+      return WM2F_EUNSUPPORTED;
+    }
+  }
   if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 3)) {
     bool handled = false;
     if (int rc = launch_quad<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
@@ -366,6 +383,12 @@ extern "C" int wm2f_msdeform_fused_packed_fwd(const void* value, const void* pac
   const int row = heads * L * P * 3;  // [offsets heads*L*P*2 | logits heads*L*P]
   bool handled = false;
   if (D == 32 && margin == 4) {
+    const float* a = (const float*)packed;
+    if (int rc = launch_stream<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, stream, who,
+                                     &handled, 0, row, row))
+      return rc;
+  }
+  if (D == 32 && margin == 4 && !handled) {
     const float* a = (const float*)packed;
     if (int rc = launch_quad<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, stream, who,
                                    &handled, 0, row, row))

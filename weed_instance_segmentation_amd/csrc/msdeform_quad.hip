@@ -164,62 +164,76 @@ __device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, i
   return p;
 }
 
-struct Group {  // the 8 corner reads of one point (2 halves x 4 corners) and its 4 weights
+// The corner reads of one point: 8 x 16 B (2 halves x 4 corners).  ONE such buffer rolls through a phase: as soon
+// as the FMA of corner i has issued, the read of the next point's corner i refills the same registers, so 7 to 8
+// reads stay in flight per wave at a cost of 32 registers (double-buffering whole points cost 72 and spilled in
+// the streaming kernel).
+struct Corners {
   float4 v[8];
+};
+struct PointAddr {  // where the quad reads a point, and its four corner weights
+  const float4 *c1, *c2;
   float q[4];
 };
 
-template <int LV, int K, int MODE>
-__device__ __forceinline__ void read_group(const float4* win, const Prod& p, int off1, int off2, Group& gr) {
-  constexpr int WW = Win<LV>::side;
+template <int LV, int K>
+__device__ __forceinline__ PointAddr point_addr(const float4* win, const Prod& p, int off1, int off2) {
+  PointAddr a;
   const int ak = bcast<K>(p.addr);
-  gr.q[0] = bcast<K>(p.w00);
-  gr.q[1] = bcast<K>(p.w01);
-  gr.q[2] = bcast<K>(p.w10);
-  gr.q[3] = bcast<K>(p.w11);
+  a.q[0] = bcast<K>(p.w00);
+  a.q[1] = bcast<K>(p.w01);
+  a.q[2] = bcast<K>(p.w10);
+  a.q[3] = bcast<K>(p.w11);
   const char* base = reinterpret_cast<const char*>(win);
-  const float4* c1 = reinterpret_cast<const float4*>(base + ak + off1);
-  const float4* c2 = reinterpret_cast<const float4*>(base + ak + off2);
+  a.c1 = reinterpret_cast<const float4*>(base + ak + off1);
+  a.c2 = reinterpret_cast<const float4*>(base + ak + off2);
+  return a;
+}
+
+template <int LV, int I, int MODE>
+__device__ __forceinline__ float4 read_corner(const PointAddr& a) {
+  constexpr int WW = Win<LV>::side;
+  constexpr int o = (I & 1) * 8 + ((I >> 1) & 1) * WW * 8;  // corner order: 00, 01, 10, 11
   if (MODE == 4) {  // ablation: no LDS reads
-    const float4 z = make_float4(gr.q[0], gr.q[1], gr.q[2], gr.q[3]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gr.v[i] = z;
-    asm volatile("" ::"v"(c1), "v"(c2));
-    return;
+    asm volatile("" ::"v"(a.c1), "v"(a.c2));
+    return make_float4(a.q[0], a.q[1], a.q[2], a.q[3]);
   }
-  gr.v[0] = c1[0];
-  gr.v[1] = c1[8];
-  gr.v[2] = c1[WW * 8];
-  gr.v[3] = c1[WW * 8 + 8];
-  gr.v[4] = c2[0];
-  gr.v[5] = c2[8];
-  gr.v[6] = c2[WW * 8];
-  gr.v[7] = c2[WW * 8 + 8];
+  return (I < 4 ? a.c1 : a.c2)[o];
 }
 
-__device__ __forceinline__ void fma_group(Acc& acc, const Group& gr) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pk_fma4(acc.a_lo, acc.a_hi, gr.q[i], gr.v[i]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pk_fma4(acc.b_lo, acc.b_hi, gr.q[i], gr.v[4 + i]);
-  // Pin the sums here: the accumulators are only stored under `if (valid)` at the very end, and
-  // LLVM's code sinking otherwise moves whole FMA chains down there (every corner then stays live
-  // across all three phases: 500+ spills).
-  asm volatile("" : "+v"(acc.a_lo), "+v"(acc.a_hi), "+v"(acc.b_lo), "+v"(acc.b_hi));
+// One level for all kPasses queries of the lane: 12 points (pass t, producer lane k), see Corners.
+template <int LV, int GI, int I, int MODE>
+__device__ __forceinline__ void corner_steps(Acc& acc, Corners& cr, const PointAddr& cur, const PointAddr& nxt) {
+  if constexpr (I < 8) {
+    if (I < 4) pk_fma4(acc.a_lo, acc.a_hi, cur.q[I & 3], cr.v[I]);
+    else pk_fma4(acc.b_lo, acc.b_hi, cur.q[I & 3], cr.v[I]);
+    if constexpr (GI + 1 < kPasses * 4) cr.v[I] = read_corner<LV, I, MODE>(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    corner_steps<LV, GI, I + 1, MODE>(acc, cr, cur, nxt);
+  }
 }
 
-// One level for all kPasses queries of the lane: 12 groups (pass t, producer lane k) in a software
-// pipeline -- the reads of group i + 1 are issued before the FMAs of group i.
 template <int LV, int GI, int MODE>
 __device__ __forceinline__ void pipe_step(const float4* win, Acc (&acc)[kPasses], const Prod (&pr)[kPasses], int off1,
-                                          int off2, Group (&gr)[2], bool skip_last) {
+                                          int off2, Corners& cr, const PointAddr& cur, bool skip_last) {
   if constexpr (GI < kPasses * 4) {
     if (GI == (kPasses - 1) * 4 && skip_last) return;  // wave-uniform: the last pass holds no query in this wave
-    if constexpr (GI + 1 < kPasses * 4) read_group<LV, (GI + 1) & 3, MODE>(win, pr[(GI + 1) >> 2], off1, off2, gr[(GI + 1) & 1]);
+    PointAddr nxt = cur;
+    if constexpr (GI + 1 < kPasses * 4) nxt = point_addr<LV, (GI + 1) & 3>(win, pr[(GI + 1) >> 2], off1, off2);
     __builtin_amdgcn_sched_barrier(0);
-    fma_group(acc[GI >> 2], gr[GI & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-    pipe_step<LV, GI + 1, MODE>(win, acc, pr, off1, off2, gr, skip_last);
+    corner_steps<LV, GI, 0, MODE>(acc[GI >> 2], cr, cur, nxt);
+    // Pin the sums here: the accumulators are only stored at the very end, and LLVM's code sinking otherwise
+    // moves whole FMA chains down there (every corner then stays live across all three phases: 500+ spills).
+    asm volatile("" : "+v"(acc[GI >> 2].a_lo), "+v"(acc[GI >> 2].a_hi), "+v"(acc[GI >> 2].b_lo), "+v"(acc[GI >> 2].b_hi));
+    pipe_step<LV, GI + 1, MODE>(win, acc, pr, off1, off2, cr, nxt, skip_last);
+  }
+}
+
+template <int LV, int I, int MODE>
+__device__ __forceinline__ void first_reads(Corners& cr, const PointAddr& a) {
+  if constexpr (I < 8) {
+    cr.v[I] = read_corner<LV, I, MODE>(a);
+    first_reads<LV, I + 1, MODE>(cr, a);
   }
 }
 
@@ -231,9 +245,11 @@ __device__ __forceinline__ void gather_phase(const float4* win, Acc (&acc)[kPass
   Prod pr[kPasses];
 #pragma unroll
   for (int t = 0; t < kPasses; ++t) pr[t] = produce<LV>(px[t][LV], py[t][LV], wt[t][LV], wx0, wy0, valid[t], slow[t]);
-  Group gr[2];
-  read_group<LV, 0, MODE>(win, pr[0], off1, off2, gr[0]);
-  pipe_step<LV, 0, MODE>(win, acc, pr, off1, off2, gr, skip_last);
+  Corners cr;
+  const PointAddr a0 = point_addr<LV, 0>(win, pr[0], off1, off2);
+  first_reads<LV, 0, MODE>(cr, a0);
+  __builtin_amdgcn_sched_barrier(0);
+  pipe_step<LV, 0, MODE>(win, acc, pr, off1, off2, cr, a0, skip_last);
 }
 
 // Slow path for one point and 4 channels: per-corner image-bounds checks, corners from global memory.
@@ -484,6 +500,386 @@ __global__ __launch_bounds__(kThreads) void msdeform_quad_fwd_kernel(const float
   WM2F_STAMP(13);
 }
 
+
+// =====================================================================================================
+// Streaming form of the kernel above: persistent workgroups, two loader waves.
+//
+// In-kernel stamps of msdeform_quad_fwd_kernel (profiles/r01_k1_quad_stamps.json): of a workgroup's 31.7k cycles
+// the three gather phases take 13.7k; 7.7k go into ISSUING the 168 LDS-DMA requests (the requests are accepted
+// at the rate the memory side delivers, ~46 cycles each, and all 8 waves sit in that queue together), 3.1k into
+// the per-tile set-up and 4.7k into barriers behind them.  None of that needs the gather waves:
+//   * one workgroup per CU stays resident and walks over its tiles (grid = CUs, XCD-contiguous tile ranges);
+//   * waves 8 and 9 only move data: they keep the window of the NEXT phase in flight while waves 0-7 gather
+//     the current one.  The three windows form the ring: while the coarse window of tile n is gathered the
+//     fine window of tile n is requested, under the mid gather the coarse window of tile n + 1, under the fine
+//     gather the mid window of tile n + 1.  Hand-over is one s_barrier per phase (10 waves), the loaders join
+//     it behind a counted vmcnt that covers exactly the window about to be read;
+//   * a loader's per-lane request offsets depend on (level, piece, lane) only: computed once into registers,
+//     a request then costs one v_add (tile origin) -- plus a column test on tiles at the left / right image
+//     border; rows above / below the image fail the descriptor's range check by themselves;
+//   * the gather waves fetch the NEXT tile's locations / weights under the fine gather of the current one,
+//     and their decode of "which query is mine" is cached while the tile shape (full / ragged) stays the same.
+// The gather waves never see an LDS-DMA in their instruction stream, so the compiler's wait insertion needs
+// no help there; the loaders never read LDS.
+constexpr int kSThreads = 640, kLoaderWave0 = 8, kLoaders = 2;
+template <int LV> struct LWin {
+  static constexpr int n = (Win<LV>::chunks + kLoaders - 1) / kLoaders;  // requests per loader: 13, 21, 43
+};
+static_assert(LWin<0>::n == 13 && LWin<1>::n == 21 && LWin<2>::n == 43, "vmcnt constants of the loader");
+
+struct StreamGeom {
+  QuadGeom q;
+  int n_logical, per_xcd, wg_per_xcd;
+  float inv_heads, inv_ntiles, inv_tiles_x;
+};
+
+// exact floor(a / d) for 0 <= a < 2^22 with inv ~ 1/d (one correction step either way)
+__device__ __forceinline__ int div_small(int a, int d, float inv) {
+  int q = (int)(((float)a + 0.5f) * inv);
+  int r = a - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; }
+  return q;
+}
+
+struct TileId {
+  int b, h, tx, ty;
+};
+__device__ __forceinline__ TileId decode_tile(int id, const StreamGeom& sg, int heads) {
+  TileId t;
+  const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
+  const int bt = div_small(id, heads, sg.inv_heads);
+  t.h = id - bt * heads;
+  t.b = div_small(bt, n_tiles, sg.inv_ntiles);
+  const int tile = bt - t.b * n_tiles;
+  t.ty = div_small(tile, sg.q.tiles_x, sg.inv_tiles_x);
+  t.tx = tile - t.ty * sg.q.tiles_x;
+  return t;
+}
+
+template <int LV>
+struct LoaderRegs {  // per-lane constants of one loader for one level
+  unsigned rel[LWin<LV>::n];  // byte offset of this lane's 16 B relative to the window origin pixel
+};
+
+template <int LV>
+__device__ __forceinline__ void loader_init(LoaderRegs<LV>& r, int ld, int Wl, int row_bytes, unsigned pix_lane,
+                                            unsigned lane_part) {
+  using W = Win<LV>;
+#pragma unroll
+  for (int i = 0; i < LWin<LV>::n; ++i) {
+    int c = ld + kLoaders * i;
+    c = c < W::chunks ? c : W::chunks - 1;
+    const unsigned idx = (unsigned)(c * 8) + pix_lane;
+    const unsigned wy = idx / (unsigned)W::side, wx = idx - wy * (unsigned)W::side;
+    r.rel[i] = __umul24(__umul24(wy, (unsigned)Wl) + wx, (unsigned)row_bytes) + lane_part;
+  }
+}
+
+// One window: LWin<LV>::n requests of this loader.  tile_off = byte offset of the window origin pixel in the
+// slab (negative above / left of the image); x_border: the window sticks out left or right.
+template <int LV>
+__device__ __forceinline__ void loader_issue(float4* win, const LoaderRegs<LV>& r, __amdgpu_buffer_rsrc_t slab, int ld,
+                                             int tile_off, bool x_border, int wx0, int Wl, unsigned pix_lane) {
+  using W = Win<LV>;
+  if (!x_border) {
+#pragma unroll
+    for (int i = 0; i < LWin<LV>::n; ++i) {
+      int c = ld + kLoaders * i;
+      c = c < W::chunks ? c : W::chunks - 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)(r.rel[i] + (unsigned)tile_off), 0, 0, 0);
+    }
+  } else {
+    // the columns are tile-invariant too, but 77 more live registers do not fit: recompute them per use (the
+    // empty asm hides the value from loop-invariant code motion)
+    asm volatile("" : "+v"(pix_lane));
+#pragma unroll
+    for (int i = 0; i < LWin<LV>::n; ++i) {
+      int c = ld + kLoaders * i;
+      c = c < W::chunks ? c : W::chunks - 1;
+      const unsigned idx = (unsigned)(c * 8) + pix_lane;
+      const int x = wx0 + (int)(idx - (idx / (unsigned)W::side) * (unsigned)W::side);
+      const unsigned off = ((unsigned)x < (unsigned)Wl) ? r.rel[i] + (unsigned)tile_off : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, 0);
+    }
+  }
+}
+
+struct LoaderTile {  // wave-uniform per-tile values of the loaders
+  __amdgpu_buffer_rsrc_t slab[3];
+  int tile_off[3], wx0[3];
+  bool x_border;
+};
+
+__device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, int id, int S, int heads) {
+  const QuadGeom& g = sg.q;
+  const TileId t = decode_tile(id, sg, heads);
+  const int row_stride = heads * 32, row_bytes = row_stride * 4, px0 = g.W0 * g.H0;
+  const float* vb = value + ((int64_t)t.b * S * heads + t.h) * 32;
+  LoaderTile lt;
+  lt.x_border = false;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const int Wl = g.W0 << l, fq = kQF >> (2 - l);
+    const int wx0 = t.tx * fq - 1 - kQM, wy0 = t.ty * fq - 1 - kQM;
+    lt.wx0[l] = wx0;
+    lt.tile_off[l] = (wy0 * Wl + wx0) * row_bytes;
+    lt.x_border = lt.x_border || wx0 < 0 || wx0 + Win<0>::side + (fq - (kQF >> 2)) > Wl;
+    const int npx = px0 << (2 * l);
+    lt.slab[l] = __builtin_amdgcn_make_buffer_rsrc((void*)(vb + (int64_t)g.start[l] * row_stride), 0,
+                                                   (npx - 1) * row_bytes + 32 * 4, 0x00020000);
+  }
+  return lt;
+}
+
+// What a gather lane knows about "its" queries for one tile shape (counts of queries per level in the tile),
+// packed: level (2 bits) | column in the tile (6 bits) | row in the tile (6 bits).
+struct Decode {
+  int code[kPasses];
+  bool valid[kPasses];
+};
+
+template <bool FUSED, int MODE>
+__global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const float* __restrict__ value,
+                                                                        const float* __restrict__ a_in,
+                                                                        const float* __restrict__ b_in,
+                                                                        float* __restrict__ out, StreamGeom sg, int S,
+                                                                        int Q, int heads) {
+  constexpr int D = 32, NL = 3, P = 4;
+  __shared__ __attribute__((aligned(16))) float4 win0[Win<0>::chunks * 64];
+  __shared__ __attribute__((aligned(16))) float4 win1[Win<1>::chunks * 64];
+  __shared__ __attribute__((aligned(16))) float4 win2[Win<2>::chunks * 64];
+  const QuadGeom& g = sg.q;
+  // this workgroup's tiles: ids first + k * stride, k < n_my (XCD-contiguous ranges, as xcd_contiguous_id)
+  const int xcd = blockIdx.x % kNumXcd, lw = blockIdx.x / kNumXcd;
+  const int range_end = min((xcd + 1) * sg.per_xcd, sg.n_logical) - xcd * sg.per_xcd;  // ids of this XCD: [0, range_end)
+  const int n_my = lw < range_end ? (range_end - lw + sg.wg_per_xcd - 1) / sg.wg_per_xcd : 0;
+  const int first = xcd * sg.per_xcd + lw, stride = sg.wg_per_xcd;
+  if (n_my <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row_stride = heads * D, row_bytes = row_stride * 4;
+
+  if (wave >= kLoaderWave0) {
+    // ------------------------------------------------------------------ loader waves
+    const int ld = wave - kLoaderWave0;
+    const unsigned pix_lane = (unsigned)lane >> 3, lane_part = ((unsigned)lane & 7u) * 16u;
+    LoaderRegs<0> r0;
+    LoaderRegs<1> r1;
+    LoaderRegs<2> r2;
+    loader_init<0>(r0, ld, g.W0, row_bytes, pix_lane, lane_part);
+    loader_init<1>(r1, ld, g.W0 << 1, row_bytes, pix_lane, lane_part);
+    loader_init<2>(r2, ld, g.W0 << 2, row_bytes, pix_lane, lane_part);
+    LoaderTile lt = loader_tile(value, sg, first, S, heads);
+    loader_issue<0>(win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+    __builtin_amdgcn_sched_barrier(0);
+    loader_issue<1>(win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+    for (int k = 0; k < n_my; ++k) {
+      const bool more = k + 1 < n_my;
+      wait_vm<LWin<1>::n>();  // coarse(k) landed; mid(k) may still fly
+      wg_barrier();           // Bc(k): gather waves are done with fine(k-1)
+      loader_issue<2>(win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      wait_vm<LWin<2>::n>();  // mid(k) landed
+      wg_barrier();           // Bm(k): gather waves are done with coarse(k)
+      if (more) {
+        lt = loader_tile(value, sg, first + (k + 1) * stride, S, heads);
+        loader_issue<0>(win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+        wait_vm<LWin<0>::n>();  // fine(k) landed
+      } else {
+        wait_vm<0>();
+      }
+      wg_barrier();  // Bf(k): gather waves are done with mid(k)
+      if (more) loader_issue<1>(win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- gather waves
+  const int j = tid & 3, quad = lane >> 2;
+  const int xq = (0x73261540 >> ((quad & 7) * 4)) & 7;  // bank-aware quad -> query order, see the kernel above
+  const int slot = wave * 16 + (quad & 8) + xq;
+  const int hq = (quad >> 2) & 1;
+  const int off1 = j * 16 + hq * 64, off2 = j * 16 + (1 - hq) * 64;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_in, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_in, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
+  const float inv_w0 = __builtin_amdgcn_rcpf((float)g.W0), inv_h0 = __builtin_amdgcn_rcpf((float)g.H0);
+
+  Decode dc;
+  int shape_key = -1;  // packed (nqx, nqy) per level of the tile shape `dc` was built for
+  // operands of a tile: raw loads + where they go
+  struct Ops {
+    float2 lc[kPasses][NL];
+    float wt[kPasses][NL];
+    int qrow[kPasses];
+    bool valid[kPasses];
+    int wx0[NL], wy0[NL], b, h;
+  };
+  // reference point of token q (HF:1127-1156): ((column + 0.5) / W_l, (row + 0.5) / H_l) of its own level
+  auto ref_point = [&](int q, float& rx, float& ry) __attribute__((always_inline)) {
+    const int l = (q >= g.start[1] ? 1 : 0) + (q >= g.start[2] ? 1 : 0);
+    const int rel = q - (l == 2 ? g.start[2] : (l == 1 ? g.start[1] : 0));
+    const int Wq = g.W0 << l;
+    const int qy = (int)(((float)rel + 0.5f) * __builtin_amdgcn_rcpf((float)Wq)) , r0 = rel - qy * Wq;
+    const int qyc = r0 < 0 ? qy - 1 : (r0 >= Wq ? qy + 1 : qy);  // one correction step: rel can exceed 2^22 / W
+    const int qx = rel - qyc * Wq;
+    const float sc = l == 2 ? 0.25f : (l == 1 ? 0.5f : 1.f);  // exact: rcp(W0 * 2^l) == rcp(W0) * 2^-l
+    rx = ((float)qx + 0.5f) * (inv_w0 * sc);
+    ry = ((float)qyc + 0.5f) * (inv_h0 * sc);
+  };
+  auto fetch = [&](int id) __attribute__((always_inline)) {
+    Ops o;
+    const TileId t = decode_tile(id, sg, heads);
+    o.b = t.b;
+    o.h = t.h;
+    int nqx[NL], nqy[NL], key = 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
+      o.wx0[l] = t.tx * fq - 1 - kQM;
+      o.wy0[l] = t.ty * fq - 1 - kQM;
+      int nx = Wl - t.tx * fq, ny = Hl - t.ty * fq;
+      nqx[l] = nx < 0 ? 0 : (nx > fq ? fq : nx);
+      nqy[l] = ny < 0 ? 0 : (ny > fq ? fq : ny);
+      key = key * 1024 + nqx[l] * 32 + nqy[l];
+    }
+    if (key != shape_key) {  // wave-uniform; interior tiles all share one shape
+      shape_key = key;
+      const int c1 = nqx[0] * nqy[0], c2 = c1 + nqx[1] * nqy[1], nq = c2 + nqx[2] * nqy[2];
+#pragma unroll
+      for (int t2 = 0; t2 < kPasses; ++t2) {
+        int qi = slot + (kThreads / 4) * t2;
+        dc.valid[t2] = qi < nq;
+        if (!dc.valid[t2]) qi = 0;
+        const bool ge1 = qi >= c1, ge2 = qi >= c2;
+        const int nx = ge2 ? nqx[2] : (ge1 ? nqx[1] : nqx[0]);
+        const int loc_i = qi - (ge2 ? c2 : (ge1 ? c1 : 0));
+        const int nxs = nx < 1 ? 1 : nx;
+        const int ly_ = (int)(((float)loc_i + 0.5f) * __builtin_amdgcn_rcpf((float)nxs));  // exact: small integers
+        dc.code[t2] = ((ge1 ? 1 : 0) + (ge2 ? 1 : 0)) | ((loc_i - ly_ * nxs) << 2) | (ly_ << 8);
+      }
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < kPasses; ++t2) {
+      const int sh = dc.code[t2] & 3;
+      const int qxi = (t.tx << (sh + 2)) + ((dc.code[t2] >> 2) & 63), qyi = (t.ty << (sh + 2)) + (dc.code[t2] >> 8);
+      const int st = sh == 2 ? g.start[2] : (sh == 1 ? g.start[1] : 0);
+      int q = st + (int)(__umul24((unsigned)qyi, (unsigned)g.W0) << sh) + qxi;
+      if (q > Q - 1) q = Q - 1;
+      o.valid[t2] = dc.valid[t2];
+      o.qrow[t2] = t.b * Q + q;
+      const int a_off = (o.qrow[t2] * g.a_qstride + t.h * (NL * P * 2) + j * 2) * 4;
+      const int b_off = (o.qrow[t2] * g.b_qstride + t.h * (NL * P) + j) * 4;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, 0));
+        o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, 0));
+      }
+    }
+    return o;
+  };
+
+  Ops nxt = fetch(first);
+  for (int k = 0; k < n_my; ++k) {
+    Ops cur = nxt;
+    // ---- per-point pixel coordinates and (fused) softmax weights
+    float px[kPasses][NL], py[kPasses][NL], wt[kPasses][NL];
+#pragma unroll
+    for (int t = 0; t < kPasses; ++t) {
+      float refx = 0.f, refy = 0.f;
+      if (FUSED) ref_point(cur.qrow[t] - cur.b * Q, refx, refy);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) wt[t][l] = cur.wt[t][l];
+      if (FUSED) {  // softmax over the 12 logits of the quad (HF:986-991)
+        const float mx = quad_max(fmaxf(fmaxf(wt[t][0], wt[t][1]), wt[t][2]));
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          wt[t][l] = __expf(wt[t][l] - mx);
+          s += wt[t][l];
+        }
+        const float inv = __builtin_amdgcn_rcpf(quad_sum(s));
+#pragma unroll
+        for (int l = 0; l < NL; ++l) wt[t][l] *= inv;
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const float Wl = (float)(g.W0 << l), Hl = (float)(g.H0 << l);
+        if (FUSED) {
+          px[t][l] = (refx * Wl - 0.5f) + cur.lc[t][l].x;
+          py[t][l] = (refy * Hl - 0.5f) + cur.lc[t][l].y;
+        } else {
+          px[t][l] = ((2.f * cur.lc[t][l].x - 1.f + 1.f) * Wl - 1.f) * 0.5f;
+          py[t][l] = ((2.f * cur.lc[t][l].y - 1.f + 1.f) * Hl - 1.f) * 0.5f;
+        }
+      }
+    }
+    Acc acc[kPasses];
+    unsigned slow[kPasses];
+#pragma unroll
+    for (int t = 0; t < kPasses; ++t) {
+      acc[t].a_lo = acc[t].a_hi = acc[t].b_lo = acc[t].b_hi = (f32x2){0.f, 0.f};
+      slow[t] = 0;
+    }
+    const bool skip_last = __builtin_amdgcn_ballot_w64(cur.valid[kPasses - 1]) == 0;
+
+    wg_barrier();  // Bc(k)
+    gather_phase<0, MODE>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
+    wg_barrier();  // Bm(k)
+    gather_phase<1, MODE>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
+    wg_barrier();  // Bf(k)
+    if (k + 1 < n_my) nxt = fetch(first + (k + 1) * stride);  // lands under the fine gather
+    __builtin_amdgcn_sched_barrier(0);
+    gather_phase<2, MODE>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
+
+    // ---- slow points (rare), then the stores
+    const float* vb = value + ((int64_t)cur.b * S * heads + cur.h) * D;
+    const bool wave_slow = __builtin_amdgcn_ballot_w64((slow[0] | slow[1] | slow[2]) != 0) != 0;
+#pragma unroll
+    for (int t = 0; t < kPasses; ++t) {
+      float4 r1 = make_float4(acc[t].a_lo.x, acc[t].a_lo.y, acc[t].a_hi.x, acc[t].a_hi.y);
+      float4 r2 = make_float4(acc[t].b_lo.x, acc[t].b_lo.y, acc[t].b_hi.x, acc[t].b_hi.y);
+      if (wave_slow && cur.valid[t]) {
+        unsigned todo = (unsigned)bcast<0>((int)slow[t]) | ((unsigned)bcast<1>((int)slow[t]) << 3) |
+                        ((unsigned)bcast<2>((int)slow[t]) << 6) | ((unsigned)bcast<3>((int)slow[t]) << 9);
+        const float* ap = a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
+        const float* bp = b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
+        float refx = 0.f, refy = 0.f, sm_max = 0.f, sm_inv = 1.f;
+        if (FUSED && todo) {  // re-derive what the fast path no longer holds in registers
+          ref_point(cur.qrow[t] - cur.b * Q, refx, refy);
+          sm_max = bp[0];
+          for (int i = 1; i < NL * P; ++i) sm_max = fmaxf(sm_max, bp[i]);
+          float ssum = 0.f;
+          for (int i = 0; i < NL * P; ++i) ssum += __expf(bp[i] - sm_max);
+          sm_inv = __builtin_amdgcn_rcpf(ssum);
+        }
+        while (todo) {  // bit (k2 * 3 + l): point k2 of level l
+          const int i = __ffs(todo) - 1;
+          todo &= todo - 1;
+          const int k2 = i / 3, l = i - k2 * 3;
+          const int Wl = g.W0 << l, Hl = g.H0 << l;
+          const int st_l = l == 0 ? g.start[0] : (l == 1 ? g.start[1] : g.start[2]);
+          const float lx = ap[(l * P + k2) * 2], ly = ap[(l * P + k2) * 2 + 1];
+          float aw = bp[l * P + k2], x, y;
+          if (FUSED) {
+            aw = __expf(aw - sm_max) * sm_inv;
+            x = (refx * (float)Wl - 0.5f) + lx;
+            y = (refy * (float)Hl - 0.5f) + ly;
+          } else {
+            x = ((2.f * lx - 1.f + 1.f) * (float)Wl - 1.f) * 0.5f;
+            y = ((2.f * ly - 1.f + 1.f) * (float)Hl - 1.f) * 0.5f;
+          }
+          const float* vlev = vb + (int64_t)st_l * row_stride;
+          quad_point_slow(r1, vlev + (off1 >> 2), Hl, Wl, row_stride, x, y, aw);
+          quad_point_slow(r2, vlev + (off2 >> 2), Hl, Wl, row_stride, x, y, aw);
+        }
+      }
+      const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4)) : kOobOffset;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, 0);
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ host side
@@ -536,6 +932,73 @@ template int launch_quad<false>(const void*, const void*, const void*, void*, co
                                 int, void*, const char*, bool*, int, int, int);
 template int launch_quad<true>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
                                int, void*, const char*, bool*, int, int, int);
+
+
+// Streaming launch: one workgroup per CU.
+template <bool FUSED>
+int launch_stream(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
+                  int Q, int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
+                  int b_qstride) {
+  *handled = false;
+  if (P != 4 || L != 3 || (int64_t)Q != S) return WM2F_OK;
+  const int H0 = level_hw[0], W0 = level_hw[1];
+  for (int l = 1; l < 3; ++l)
+    if (level_hw[2 * l] != (H0 << l) || level_hw[2 * l + 1] != (W0 << l)) return WM2F_OK;
+  if (H0 < 1 || W0 < 1 || (int64_t)H0 * W0 * 21 != S) return WM2F_OK;
+  StreamGeom sg;
+  QuadGeom& g = sg.q;
+  g.W0 = W0;
+  g.H0 = H0;
+  g.tiles_x = (4 * W0 + kQF - 1) / kQF;
+  g.tiles_y = (4 * H0 + kQF - 1) / kQF;
+  g.start[0] = 0;
+  g.start[1] = H0 * W0;
+  g.start[2] = 5 * H0 * W0;
+  g.a_qstride = a_qstride > 0 ? a_qstride : heads * L * P * 2;
+  g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
+  const int64_t n_logical = (int64_t)B * heads * g.tiles_x * g.tiles_y;
+  const int64_t lim = 0x7fffffff;
+  if (n_logical >= (1 << 22) || (int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
+      (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)16 * H0 * W0 >= (1 << 24) || heads * 32 * 4 >= (1 << 24) ||
+      (int64_t)21 * H0 * W0 * heads * 32 * 4 >= lim)
+    return WM2F_OK;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      set_error("%s: cannot query the device", who);
+      return WM2F_ELAUNCH;
+    }
+    n_cu = prop.multiProcessorCount;
+  }
+  int wg = n_cu - n_cu % kNumXcd;  // a multiple of the XCD count
+  if (wg < kNumXcd) wg = kNumXcd;
+  sg.n_logical = (int)n_logical;
+  sg.per_xcd = (int)ceil_div64(n_logical, kNumXcd);
+  sg.wg_per_xcd = wg / kNumXcd;
+  if (sg.wg_per_xcd > sg.per_xcd) sg.wg_per_xcd = sg.per_xcd;
+  wg = sg.wg_per_xcd * kNumXcd;
+  sg.inv_heads = 1.f / (float)heads;
+  sg.inv_ntiles = 1.f / (float)(g.tiles_x * g.tiles_y);
+  sg.inv_tiles_x = 1.f / (float)g.tiles_x;
+  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0>;
+  if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4>;
+  hipLaunchKernelGGL(kfn, dim3(wg), dim3(kSThreads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
+                     (const float*)b, (float*)out, sg, S, Q, heads);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: streaming launch failed: %s", who, hipGetErrorString(e));
+    return WM2F_ELAUNCH;
+  }
+  *handled = true;
+  return WM2F_OK;
+}
+
+template int launch_stream<false>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
+                                  int, void*, const char*, bool*, int, int, int);
+template int launch_stream<true>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
+                                 int, void*, const char*, bool*, int, int, int);
 
 }  // namespace wm2f
 
