@@ -31,9 +31,24 @@ def main():
     for _ in range(3):
         ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
     torch.cuda.synchronize()
-    n_wg = B * H * 64
+    n_wg = B * H * 64 if a.variant == 73 else torch.cuda.get_device_properties(0).multi_processor_count
     buf = np.zeros((min(n_wg, 8192), 16), dtype=np.int64)
     check(load().wm2f_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "wm2f_debug_stamps")
+    if a.variant == 74:  # streaming kernel: second tile of every workgroup; slots 0-9 gather wave 0, 10-15 loader wave 8
+        g_names = ["coords/softmax", "Bc wait", "gather coarse", "Bm wait", "gather mid", "Bf wait", "fetch next operands",
+                   "gather fine", "slow+stores"]
+        l_names = ["Bc wait", "issue fine", "wait mid + Bm wait", "issue coarse(next) + wait fine", "Bf wait"]
+        st = buf.astype(np.float64)
+        out = {"ticks": "s_memtime", "workgroups": int(st.shape[0])}
+        dg = np.diff(st[:, :10], axis=1)
+        for i, n in enumerate(g_names):
+            out["gather: " + n] = [float(np.percentile(dg[:, i], q)) for q in (10, 50, 90)]
+        out["gather: tile span"] = [float(np.percentile(st[:, 9] - st[:, 0], q)) for q in (10, 50, 90)]
+        dl = np.diff(st[:, 10:16], axis=1)
+        for i, n in enumerate(l_names):
+            out["loader: " + n] = [float(np.percentile(dl[:, i], q)) for q in (10, 50, 90)]
+        print(json.dumps(out, indent=1))
+        return
     st = buf[:, :14].astype(np.float64)
     d = np.diff(st, axis=1)
     out = {"ticks": "s_memtime", "workgroups": int(st.shape[0])}

@@ -40,7 +40,7 @@ def main():
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device="cpu").manual_seed(0)
     res = {}
-    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1b")):
+    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1s", "k1b")):
         value = torch.randn(B, S, H, D, device=dev)
         # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
@@ -77,8 +77,8 @@ def main():
                 o.backward(go)
                 vv.grad = ll.grad = ww_.grad = None
             res["k1_fwd_plus_bwd"] = timeit(fb, a.iters)
-        if "k1t" in only or "k1q" in only:  # one variant only, for PMC runs (k1t: LDS-window kernel, k1q: phased quad kernel)
-            vv_ = 2 if "k1t" in only else 3
+        if "k1t" in only or "k1q" in only or "k1s" in only:  # one variant only, for PMC runs (LDS-window / phased quad / streaming)
+            vv_ = 2 if "k1t" in only else (3 if "k1q" in only else 4)
             r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=vv_, margin=4), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
             res[f"k1_fused_variant{vv_}_margin4"] = r

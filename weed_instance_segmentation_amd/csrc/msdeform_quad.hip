@@ -521,11 +521,23 @@ __global__ __launch_bounds__(kThreads) void msdeform_quad_fwd_kernel(const float
 //     and their decode of "which query is mine" is cached while the tile shape (full / ragged) stays the same.
 // The gather waves never see an LDS-DMA in their instruction stream, so the compiler's wait insertion needs
 // no help there; the loaders never read LDS.
-constexpr int kSThreads = 640, kLoaderWave0 = 8, kLoaders = 2;
+#ifndef WM2F_STREAM_GATHER_WAVES
+#define WM2F_STREAM_GATHER_WAVES 8
+#endif
+constexpr int kGatherWaves = WM2F_STREAM_GATHER_WAVES;  // 8 or 10 (10: 3 waves on every SIMD at the same 168 registers; measured 3 % slower)
+constexpr int kSThreads = (kGatherWaves + 2) * 64, kLoaderWave0 = kGatherWaves, kLoaders = 2;
 template <int LV> struct LWin {
   static constexpr int n = (Win<LV>::chunks + kLoaders - 1) / kLoaders;  // requests per loader: 13, 21, 43
 };
 static_assert(LWin<0>::n == 13 && LWin<1>::n == 21 && LWin<2>::n == 43, "vmcnt constants of the loader");
+
+// MODE 7 stamps of the streaming kernel: the workgroup's SECOND tile (steady state); slots 0-9 by wave 0 (gather),
+// 10-15 by wave 8 (loader).
+#define WM2F_SSTAMP(slot, who)                                                                              \
+  do {                                                                                                      \
+    if (MODE == 7 && k == 1 && tid == (who) * 64 && blockIdx.x < kStampGroups)                              \
+      g_stamps[blockIdx.x * kStampSlots + (slot)] = (long long)__builtin_readcyclecounter();                \
+  } while (0)
 
 struct StreamGeom {
   QuadGeom q;
@@ -576,15 +588,18 @@ __device__ __forceinline__ void loader_init(LoaderRegs<LV>& r, int ld, int Wl, i
   }
 }
 
-// One window: LWin<LV>::n requests of this loader.  tile_off = byte offset of the window origin pixel in the
+// Requests [I0, I1) of this loader for one window.  tile_off = byte offset of the window origin pixel in the
 // slab (negative above / left of the image); x_border: the window sticks out left or right.
-template <int LV>
-__device__ __forceinline__ void loader_issue(float4* win, const LoaderRegs<LV>& r, __amdgpu_buffer_rsrc_t slab, int ld,
+typedef __attribute__((address_space(3))) float4* lds4_t;  // an LDS pointer that never passes through a generic one
+
+template <int LV, int I0, int I1>
+__device__ __forceinline__ void loader_issue(lds4_t win, const LoaderRegs<LV>& r, __amdgpu_buffer_rsrc_t slab, int ld,
                                              int tile_off, bool x_border, int wx0, int Wl, unsigned pix_lane) {
   using W = Win<LV>;
+  static_assert(I0 >= 0 && I1 <= LWin<LV>::n, "request range");
   if (!x_border) {
 #pragma unroll
-    for (int i = 0; i < LWin<LV>::n; ++i) {
+    for (int i = I0; i < I1; ++i) {
       int c = ld + kLoaders * i;
       c = c < W::chunks ? c : W::chunks - 1;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)(r.rel[i] + (unsigned)tile_off), 0, 0, 0);
@@ -594,7 +609,7 @@ __device__ __forceinline__ void loader_issue(float4* win, const LoaderRegs<LV>& 
     // empty asm hides the value from loop-invariant code motion)
     asm volatile("" : "+v"(pix_lane));
 #pragma unroll
-    for (int i = 0; i < LWin<LV>::n; ++i) {
+    for (int i = I0; i < I1; ++i) {
       int c = ld + kLoaders * i;
       c = c < W::chunks ? c : W::chunks - 1;
       const unsigned idx = (unsigned)(c * 8) + pix_lane;
@@ -669,27 +684,46 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     loader_init<0>(r0, ld, g.W0, row_bytes, pix_lane, lane_part);
     loader_init<1>(r1, ld, g.W0 << 1, row_bytes, pix_lane, lane_part);
     loader_init<2>(r2, ld, g.W0 << 2, row_bytes, pix_lane, lane_part);
+    // Schedule (per loader; F = fine window split in two parts so that no phase carries much more than a third of
+    // a tile's requests -- the requests are accepted at the memory side's pace, ~100 cycles each per loader, and
+    // the gather waves wait for the loader at every barrier):
+    //   under the coarse gather of tile k:  F(k) part A                      (26 requests)
+    //   under the mid gather:               F(k) part B, coarse(k + 1)       (17 + 13)
+    //   under the fine gather:              [pause: the gather waves fetch their next operands]  mid(k + 1)  (21)
+    constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
     LoaderTile lt = loader_tile(value, sg, first, S, heads);
-    loader_issue<0>(win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+    loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
     __builtin_amdgcn_sched_barrier(0);
-    loader_issue<1>(win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+    loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
     for (int k = 0; k < n_my; ++k) {
       const bool more = k + 1 < n_my;
       wait_vm<LWin<1>::n>();  // coarse(k) landed; mid(k) may still fly
+      WM2F_SSTAMP(10, kLoaderWave0);
       wg_barrier();           // Bc(k): gather waves are done with fine(k-1)
-      loader_issue<2>(win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
-      wait_vm<LWin<2>::n>();  // mid(k) landed
-      wg_barrier();           // Bm(k): gather waves are done with coarse(k)
+      WM2F_SSTAMP(11, kLoaderWave0);
+      loader_issue<2, 0, kFA>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      WM2F_SSTAMP(12, kLoaderWave0);
+      wait_vm<kFA>();  // mid(k) landed
+      wg_barrier();    // Bm(k): gather waves are done with coarse(k)
+      WM2F_SSTAMP(13, kLoaderWave0);
+      loader_issue<2, kFA, LWin<2>::n>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
       if (more) {
         lt = loader_tile(value, sg, first + (k + 1) * stride, S, heads);
-        loader_issue<0>(win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+        __builtin_amdgcn_sched_barrier(0);
+        loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
         wait_vm<LWin<0>::n>();  // fine(k) landed
       } else {
         wait_vm<0>();
       }
+      WM2F_SSTAMP(14, kLoaderWave0);
       wg_barrier();  // Bf(k): gather waves are done with mid(k)
-      if (more) loader_issue<1>(win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+      WM2F_SSTAMP(15, kLoaderWave0);
+      if (more) {
+        __builtin_amdgcn_s_sleep(24);  // ~1.5k cycles: leave the memory path to the gather waves' operand loads
+        loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+      }
     }
+    (void)kFB;
     return;
   }
 
@@ -747,7 +781,12 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       const int c1 = nqx[0] * nqy[0], c2 = c1 + nqx[1] * nqy[1], nq = c2 + nqx[2] * nqy[2];
 #pragma unroll
       for (int t2 = 0; t2 < kPasses; ++t2) {
-        int qi = slot + (kThreads / 4) * t2;
+        // passes 0, 1: all 8 gather waves; the third pass of a full tile (80 queries) goes to waves 0-3 and 7:
+        // the loaders share their SIMDs with waves (0, 4) and (1, 5) (waves go to SIMDs cyclically), so waves 4
+        // and 5 -- and 6, whose SIMD then carries 3 + 2 passes -- stay at two passes
+        // With 10 gather waves two passes cover 320 queries and wave 2 takes the last 16.
+        const int w3 = kGatherWaves == 8 ? (wave < 4 ? wave : (wave == 7 ? 4 : 1 << 20)) : (wave == 2 ? 0 : 1 << 20);
+        int qi = t2 < 2 ? slot + (kGatherWaves * 16) * t2 : 2 * (kGatherWaves * 16) + w3 * 16 + (quad & 8) + xq;
         dc.valid[t2] = qi < nq;
         if (!dc.valid[t2]) qi = 0;
         const bool ge1 = qi >= c1, ge2 = qi >= c2;
@@ -781,6 +820,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
   Ops nxt = fetch(first);
   for (int k = 0; k < n_my; ++k) {
     Ops cur = nxt;
+    WM2F_SSTAMP(0, 0);
     // ---- per-point pixel coordinates and (fused) softmax weights
     float px[kPasses][NL], py[kPasses][NL], wt[kPasses][NL];
 #pragma unroll
@@ -822,14 +862,22 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     }
     const bool skip_last = __builtin_amdgcn_ballot_w64(cur.valid[kPasses - 1]) == 0;
 
+    WM2F_SSTAMP(1, 0);
     wg_barrier();  // Bc(k)
+    WM2F_SSTAMP(2, 0);
     gather_phase<0, MODE>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
+    WM2F_SSTAMP(3, 0);
     wg_barrier();  // Bm(k)
+    WM2F_SSTAMP(4, 0);
     gather_phase<1, MODE>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
+    WM2F_SSTAMP(5, 0);
     wg_barrier();  // Bf(k)
+    WM2F_SSTAMP(6, 0);
     if (k + 1 < n_my) nxt = fetch(first + (k + 1) * stride);  // lands under the fine gather
     __builtin_amdgcn_sched_barrier(0);
+    WM2F_SSTAMP(7, 0);
     gather_phase<2, MODE>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
+    WM2F_SSTAMP(8, 0);
 
     // ---- slow points (rare), then the stores
     const float* vb = value + ((int64_t)cur.b * S * heads + cur.h) * D;
@@ -877,6 +925,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, 0);
     }
+    WM2F_SSTAMP(9, 0);
   }
 }
 
@@ -984,6 +1033,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
   auto kfn = msdeform_stream_fwd_kernel<FUSED, 0>;
   if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4>;
+  if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7>;
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(kSThreads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();
