@@ -184,6 +184,32 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
                        const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
                        int64_t pos_rows, float eps, void* stream);
 
+/* ---- instance post-processing on device ----------------------------------
+ * Replaces the tensor work of Mask2FormerImageProcessor.post_process_instance_segmentation,
+ * transformers 5.15.0 models/mask2former/image_processing_mask2former.py:627-746 (callers: reference
+ * models/metrics.py:58-63, models/mask2former/inference.py:30).  The dependency resizes the logits to a fixed
+ * gh x gw = 384 x 384 grid (bilinear, :680-682); these kernels evaluate that resize on the fly.
+ *   mask_logits (B, Q, h, w) fp32; qidx (B, K) int32 DEVICE: the source query of each selected (query, class)
+ *   pair (:698-702).
+ * wm2f_instance_scores:        sum_sig[b,k] = sum sigmoid(l) over grid pixels with l > 0, cnt[b,k] = their number
+ *                              (:703-708: mask score = sum_sig / (cnt + 1e-6)).
+ * wm2f_instance_any:           any_out[b,k] = does the `nearest`-resized (Ho x Wo) mask have a set pixel (:715-717,
+ *                              :724); evaluated only where cand[b,k] != 0.
+ * wm2f_instance_segmentation:  segmentation (B, Ho, Wo) fp32: id r of the LAST kept instance covering the pixel,
+ *                              -1 elsewhere (:712-735).  kept_q (B, K) int32: source query of kept instance r,
+ *                              n_kept (B) int32, both DEVICE.
+ * wm2f_instance_maps:          the kept binary masks of ONE image, (n, Ho, Wo) fp32 0/1 (return_binary_maps, :741-743);
+ *                              image_logits = that image's (Q, h, w) slab. */
+int wm2f_instance_scores(const void* mask_logits, const int32_t* qidx, void* sum_sig, void* cnt, int B, int Q,
+                         int K, int h, int w, int gh, int gw, void* stream);
+int wm2f_instance_any(const void* mask_logits, const int32_t* qidx, const uint8_t* cand, int32_t* any_out, int B,
+                      int Q, int K, int h, int w, int gh, int gw, int Ho, int Wo, void* stream);
+int wm2f_instance_segmentation(const void* mask_logits, const int32_t* kept_q, const int32_t* n_kept,
+                               void* segmentation, int B, int Q, int K, int h, int w, int gh, int gw, int Ho,
+                               int Wo, void* stream);
+int wm2f_instance_maps(const void* image_logits, const int32_t* kept_q, int n, void* maps, int h, int w, int gh,
+                       int gw, int Ho, int Wo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

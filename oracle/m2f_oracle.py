@@ -456,3 +456,42 @@ def forward(sd, cfg, pixel_values, mask_labels=None, class_labels=None, rand_sou
             loss, ld, idx = criterion(all_masks, all_classes, mask_labels, class_labels, rs, cfg)
             res.update(loss=loss, loss_dict=ld, indices=idx)
         return res
+
+
+# --------------------------------------------------------------------------------------------------
+# Instance post-processing: restates Mask2FormerImageProcessor.post_process_instance_segmentation,
+# transformers 5.15.0 models/mask2former/image_processing_mask2former.py:627-746 (identical text in
+# image_processing_pil_mask2former.py:665-785).  Pinned by tests/golden/postprocess_instances.npz, which the
+# dependency's own function produced.
+def post_process_instance_segmentation(class_queries_logits, masks_queries_logits, threshold=0.5, target_sizes=None,
+                                       return_binary_maps=False):
+    masks = F.interpolate(masks_queries_logits.float(), size=(384, 384), mode="bilinear", align_corners=False)  # :680-682
+    B, Q = class_queries_logits.shape[:2]
+    C = class_queries_logits.shape[-1] - 1
+    results = []
+    for i in range(B):
+        scores = F.softmax(class_queries_logits[i].float(), dim=-1)[:, :-1]  # :695
+        labels = torch.arange(C).unsqueeze(0).repeat(Q, 1).flatten(0, 1)
+        s, idx = scores.flatten(0, 1).topk(Q, sorted=False)  # :698 -- the order of this routine is the paint order
+        lab = labels[idx]
+        qi = torch.div(idx, C, rounding_mode="floor")
+        mp = masks[i][qi]
+        pm = (mp > 0).float()  # :703
+        ms = (mp.sigmoid().flatten(1) * pm.flatten(1)).sum(1) / (pm.flatten(1).sum(1) + 1e-6)  # :706-708
+        ps = s * ms
+        seg = torch.zeros((384, 384)) - 1
+        if target_sizes is not None:
+            seg = torch.zeros(tuple(target_sizes[i])) - 1
+            pm = F.interpolate(pm.unsqueeze(0), size=tuple(target_sizes[i]), mode="nearest")[0]  # :715-717
+        segments, maps, cur = [], [], 0
+        for j in range(Q):  # :721-735
+            score = ps[j].item()
+            if not torch.all(pm[j] == 0) and score >= threshold:
+                seg[pm[j] == 1] = cur
+                segments.append({"id": cur, "label_id": int(lab[j]), "was_fused": False, "score": round(score, 6)})
+                cur += 1
+                maps.append(pm[j])
+        if return_binary_maps and maps:
+            seg = torch.stack(maps, 0)
+        results.append({"segmentation": seg, "segments_info": segments})
+    return results

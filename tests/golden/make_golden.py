@@ -367,6 +367,43 @@ def gen_swin():
     save("swin_tiny_backbone.npz", **arrays)
 
 
+def gen_postprocess():
+    """Outputs of the dependency's own post_process_instance_segmentation (CPU) on small synthetic logits:
+    three images, three target-size regimes (smaller than the 384 grid, larger, none) + the binary-map variant."""
+    from types import SimpleNamespace
+    # torchvision is absent here, so the torchvision-backed Mask2FormerImageProcessor does not import; the PIL-backed
+    # class of the same package carries the same post_process_instance_segmentation (:665-785 of its file)
+    from transformers.models.mask2former.image_processing_pil_mask2former import Mask2FormerImageProcessorPil
+    proc = Mask2FormerImageProcessorPil()
+    g = torch.Generator().manual_seed(31)
+    B, Q, C, h, w = 3, 12, 3, 32, 40
+    low = torch.randn(B, Q, 5, 6, generator=g) * 4.0 - 1.0
+    masks = torch.nn.functional.interpolate(low, size=(h, w), mode="bicubic", align_corners=False) + 0.3 * torch.randn(B, Q, h, w, generator=g)
+    masks[0, 3] = -5.0  # an empty mask
+    cls = torch.randn(B, Q, C + 1, generator=g) * 4.0
+    cls[1, :, :] = -3.0
+    cls[1, :, -1] = 3.0  # image 1: nothing above threshold
+    cls[1, 2, 1] = 9.0   # ... except one query
+    out = SimpleNamespace(class_queries_logits=cls, masks_queries_logits=masks)
+    arrays = {"class_logits": cls, "mask_logits": masks}
+    info = {}
+    for tag, ts in (("none", None), ("mixed", [(50, 70), (400, 500), (384, 384)]), ("small", [(33, 47)] * 3)):
+        res = proc.post_process_instance_segmentation(out, threshold=0.5, mask_threshold=0.5, target_sizes=ts)
+        for i, r in enumerate(res):
+            arrays[f"seg_{tag}_{i}"] = r["segmentation"].to(torch.int16)
+        info[tag] = {"target_sizes": ts, "segments_info": [r["segments_info"] for r in res]}
+    res = proc.post_process_instance_segmentation(out, threshold=0.5, target_sizes=[(50, 70)] * 3, return_binary_maps=True)
+    for i, r in enumerate(res):
+        arrays[f"maps_{i}"] = r["segmentation"].to(torch.int16)
+    info["maps"] = {"target_sizes": [(50, 70)] * 3, "segments_info": [r["segments_info"] for r in res]}
+    res = proc.post_process_instance_segmentation(out, threshold=0.5, target_sizes=[(20, 24)] * 3, return_coco_annotation=True)
+    info["rle"] = {"target_sizes": [(20, 24)] * 3, "segments_info": [r["segments_info"] for r in res],
+                   "segmentation": [r["segmentation"] for r in res]}
+    arrays["info_json"] = np.asarray(json.dumps(info, default=lambda o: int(o)))
+    save("postprocess_instances.npz", **arrays)
+    print("kept per image:", [len(x) for x in info["mixed"]["segments_info"]])
+
+
 def gen_state_keys():
     from transformers import SwinConfig
     res = {}
@@ -386,8 +423,8 @@ def gen_state_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1", "a2", "k2", "k3", "k4", "full", "keys", "swin"]
+    which = sys.argv[1:] or ["k1", "a2", "k2", "k3", "k4", "full", "keys", "swin", "post"]
     torch.set_num_threads(8)
     for w in which:
         {"k1": gen_k1, "a2": gen_a2, "k2": gen_k2, "k3": gen_k3, "k4": gen_k4, "full": gen_full,
-         "keys": gen_state_keys, "swin": gen_swin}[w]()
+         "keys": gen_state_keys, "swin": gen_swin, "post": gen_postprocess}[w]()

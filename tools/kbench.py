@@ -86,6 +86,31 @@ def main():
             r = timeit(lambda: ops.ms_deform_attn_fused(value, shapes, off, logits, refl), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
             res["k1_msdeform_fused_fwd"] = r
+    if "pp" in only:  # instance post-processing at the reference's eval shape (Q = 100, 256^2 logits -> 1024^2 targets)
+        import time
+        from types import SimpleNamespace
+        from weed_instance_segmentation_amd.postprocess import Mask2FormerInstancePostProcessor
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import m2f_oracle as O
+        gg = torch.Generator().manual_seed(5)
+        low = torch.randn(B, Q, 8, 8, generator=gg) * 3.0 - 2.0
+        masks = torch.nn.functional.interpolate(low, size=(256, 256), mode="bicubic", align_corners=False)
+        cls = torch.randn(B, Q, 4, generator=gg) * 3.0
+        ts = [(1024, 1024)] * B
+        out = SimpleNamespace(class_queries_logits=cls.to(dev), masks_queries_logits=masks.to(dev))
+        proc = Mask2FormerInstancePostProcessor()
+        proc.post_process_instance_segmentation(out, threshold=0.5, target_sizes=ts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r = proc.post_process_instance_segmentation(out, threshold=0.5, target_sizes=ts)
+        torch.cuda.synchronize()
+        t_hip = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        ref = O.post_process_instance_segmentation(cls, masks, 0.5, ts)
+        t_cpu = time.perf_counter() - t0
+        res["postprocess_instances"] = {"hip_ms_per_batch": t_hip * 1e3, "oracle_cpu_ms_per_batch": t_cpu * 1e3, "B": B,
+                                        "kept": sum(len(x["segments_info"]) for x in r), "cpu_threads": torch.get_num_threads()}
     if "k3" in only or "mask" in only:
         emb = torch.randn(B, Q, 256, device=dev)
         pix = torch.randn(B, 256, 256, 256, device=dev)

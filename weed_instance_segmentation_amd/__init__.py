@@ -10,3 +10,4 @@ from .configuration import Mask2FormerConfig  # noqa: F401
 from .modeling import Mask2FormerForUniversalSegmentation, Mask2FormerForUniversalSegmentationOutput  # noqa: F401
 
 __version__ = "0.1.0"
+from .postprocess import Mask2FormerInstancePostProcessor  # noqa: F401

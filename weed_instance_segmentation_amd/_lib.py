@@ -28,6 +28,10 @@ SIGNATURES = {
     "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_debug_stamps": (c_int, [_P, c_int64]),
+    "wm2f_instance_scores": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_instance_any": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_instance_segmentation": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_instance_maps": (c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_mask_einsum_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_masked_xattn_workspace": (c_int64, [_I, _I, _I, _I, _I]),

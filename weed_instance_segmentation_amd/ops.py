@@ -385,3 +385,54 @@ def add_layernorm(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None
         check(load().wm2f_add_layernorm(_p(x), _p(residual), _p(gamma), _p(beta), _p(pos), _p(out), _p(out_pos), rows, C,
                                         pos_rows, float(eps), _stream(x)), "wm2f_add_layernorm")
     return (out, out_pos) if pos is not None else out
+
+
+# ------------------------------------------------------------------ instance post-processing
+_GRID = (384, 384)  # the dependency's hard-coded intermediate size (image_processing_mask2former.py:680-682)
+
+
+def instance_scores(mask_logits: torch.Tensor, qidx: torch.Tensor):
+    """(sum of sigmoid over set pixels, number of set pixels) of each selected query's mask on the 384 x 384 grid."""
+    mask_logits, qidx = _req(mask_logits, "mask_logits"), _req(qidx, "qidx", torch.int32)
+    B, Q, h, w = mask_logits.shape
+    K = qidx.shape[1]
+    s = torch.empty(B, K, device=mask_logits.device, dtype=torch.float32)
+    c = torch.empty_like(s)
+    with torch.cuda.device(mask_logits.device):
+        check(load().wm2f_instance_scores(_p(mask_logits), _p(qidx), _p(s), _p(c), B, Q, K, h, w, _GRID[0], _GRID[1],
+                                          _stream(mask_logits)), "wm2f_instance_scores")
+    return s, c
+
+
+def instance_any(mask_logits, qidx, cand, size):
+    mask_logits, qidx, cand = _req(mask_logits, "mask_logits"), _req(qidx, "qidx", torch.int32), _req(cand, "cand", torch.uint8)
+    B, Q, h, w = mask_logits.shape
+    K = qidx.shape[1]
+    out = torch.empty(B, K, device=mask_logits.device, dtype=torch.int32)
+    with torch.cuda.device(mask_logits.device):
+        check(load().wm2f_instance_any(_p(mask_logits), _p(qidx), _p(cand), _p(out), B, Q, K, h, w, _GRID[0], _GRID[1],
+                                       int(size[0]), int(size[1]), _stream(mask_logits)), "wm2f_instance_any")
+    return out
+
+
+def instance_segmentation(mask_logits, kept_q, n_kept, size):
+    mask_logits = _req(mask_logits, "mask_logits")
+    kept_q, n_kept = _req(kept_q, "kept_q", torch.int32), _req(n_kept, "n_kept", torch.int32)
+    B, Q, h, w = mask_logits.shape
+    K = kept_q.shape[1]
+    seg = torch.empty(B, int(size[0]), int(size[1]), device=mask_logits.device, dtype=torch.float32)
+    with torch.cuda.device(mask_logits.device):
+        check(load().wm2f_instance_segmentation(_p(mask_logits), _p(kept_q), _p(n_kept), _p(seg), B, Q, K, h, w, _GRID[0],
+                                                _GRID[1], int(size[0]), int(size[1]), _stream(mask_logits)),
+              "wm2f_instance_segmentation")
+    return seg
+
+
+def instance_maps(image_logits, kept_q, n, size):
+    image_logits, kept_q = _req(image_logits, "image_logits"), _req(kept_q, "kept_q", torch.int32)
+    Q, h, w = image_logits.shape
+    maps = torch.empty(n, int(size[0]), int(size[1]), device=image_logits.device, dtype=torch.float32)
+    with torch.cuda.device(image_logits.device):
+        check(load().wm2f_instance_maps(_p(image_logits), _p(kept_q), int(n), _p(maps), h, w, _GRID[0], _GRID[1],
+                                        int(size[0]), int(size[1]), _stream(image_logits)), "wm2f_instance_maps")
+    return maps
