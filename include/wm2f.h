@@ -145,7 +145,7 @@ int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v, const voi
  * Replaces Mask2FormerHungarianMatcher.forward up to (not including) the scipy solver,
  * HF:444-472 with sample_point HF:245-274 and the pair-wise losses HF:328-374, batched over
  * NL prediction levels and B images so that ONE device->host copy feeds every solver call.
- *   mask_logits  (NL, B, Q, h, w) fp32           class_logits (NL, B, Q, C1) fp32
+ *   mask_logits  (NL, B, Q, h, w) fp32, NL <= 16   class_logits (NL, B, Q, C1) fp32
  *   tgt_masks    concatenation over images of (T_i, Ht, Wt); tgt_dtype 0 = fp32, 1 = uint8
  *   tgt_offset   host int32 [B+1]: image i owns targets [tgt_offset[i], tgt_offset[i+1])
  *   tgt_classes  int64 [sum T_i]
@@ -161,6 +161,13 @@ int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const v
                       const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1,
                       int h, int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask,
                       float w_dice, void* stream);
+/* The same with the levels NOT stacked: mask_levels = HOST array of NL (<= 16) DEVICE pointers, each (B, Q, h, w) fp32
+ * (the mask predictor's outputs where they are; a stacked copy is 10 x 210 MB at config 2). */
+int wm2f_matcher_cost_levels(const void* const* mask_levels, const void* class_logits, const void* tgt_masks,
+                             int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes,
+                             const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1, int h,
+                             int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                             void* stream);
 
 /* ---- point sampling (shared by the loss, HF:245-274) ----------------------------------------
  *   feat (N, H, W) fp32 or uint8 (feat_dtype 0 / 1); pts (M, P, 2); out (M, P) fp32.
@@ -183,6 +190,26 @@ int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y
 int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,
                        const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
                        int64_t pos_rows, float eps, void* stream);
+
+/* ---- point-sampled mask loss, batched over the prediction levels --------
+ * Replaces, for all levels of a step in one launch each, the per-level tensor work of Mask2FormerLoss.loss_masks
+ * (HF:580-640) with sample_points_using_uncertainty (HF:671-724), sample_point (HF:245-274),
+ * sigmoid_cross_entropy_loss (HF:308-324) and dice_loss (HF:278-305).
+ *   level_maps / level_grads: HOST array of n_levels (<= 16) DEVICE pointers, each (N, H, W) fp32 -- the level
+ *   tensors are used where they are, not stacked.   pts (n_levels, M, P, 2) in [0,1] (x, y); index (n_levels, M)
+ *   int32 DEVICE: which map of its level row m samples.
+ * wm2f_point_sample_levels_fwd: out (n_levels, M, P); neg_abs != 0 stores -|value| (the uncertainty, HF:688-690).
+ * wm2f_point_sample_levels_bwd: atomically adds grad_out * bilinear weights into the (zero-initialised) level_grads.
+ * wm2f_mask_loss_rows_fwd:      logits, labels (R, P) -> bce_mean (R), dice (R), sums (R, 4) kept for the backward.
+ * wm2f_mask_loss_rows_bwd:      grad (R, P) = g_bce[r] * d bce_mean[r] + g_dice[r] * d dice[r]. */
+int wm2f_point_sample_levels_fwd(const void* const* level_maps, int n_levels, const void* pts, const int32_t* index,
+                                 void* out, int M, int H, int W, int P, int neg_abs, void* stream);
+int wm2f_point_sample_levels_bwd(const void* grad_out, const void* pts, const int32_t* index,
+                                 void* const* level_grads, int n_levels, int M, int H, int W, int P, void* stream);
+int wm2f_mask_loss_rows_fwd(const void* logits, const void* labels, void* sums, void* bce_mean, void* dice,
+                            int R, int P, void* stream);
+int wm2f_mask_loss_rows_bwd(const void* logits, const void* labels, const void* sums, const void* g_bce,
+                            const void* g_dice, void* grad, int R, int P, void* stream);
 
 /* ---- instance post-processing on device ----------------------------------
  * Replaces the tensor work of Mask2FormerImageProcessor.post_process_instance_segmentation,

@@ -52,9 +52,12 @@ def test_forward_matches_golden(tiny):
 
 
 @pytest.mark.parametrize("label_dtype", [torch.float32, torch.uint8])
-def test_loss_and_indices_match_golden(tiny, label_dtype):
+@pytest.mark.parametrize("batched", [True, False])
+def test_loss_and_indices_match_golden(tiny, label_dtype, batched):
+    """Both loss paths: all levels in one pass (loss_masks_all_levels, the default) and one pass per level."""
     from weed_instance_segmentation_amd.loss import ReplayPointProvider
     g, cfg, model, _ = tiny
+    model.criterion.batched_levels = batched
     B = g["pixel_values"].shape[0]
     ml, cl = _labels(g, B, dtype=label_dtype)
     n_layers = cfg.decoder_layers - 1
@@ -67,6 +70,7 @@ def test_loss_and_indices_match_golden(tiny, label_dtype):
     for k, v in out.loss_dict.items():
         torch.testing.assert_close(v.cpu(), T(g["ld." + k]), rtol=2e-3, atol=1e-4)
     torch.testing.assert_close(out.loss.cpu(), T(g["loss"]), rtol=1e-3, atol=1e-3)
+    model.criterion.batched_levels = True
 
 
 def test_forward_matches_oracle_other_input(tiny):

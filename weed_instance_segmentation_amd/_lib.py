@@ -28,6 +28,10 @@ SIGNATURES = {
     "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_debug_stamps": (c_int, [_P, c_int64]),
+    "wm2f_point_sample_levels_fwd": (c_int, [POINTER(c_void_p), _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm2f_point_sample_levels_bwd": (c_int, [_P, _P, _P, POINTER(c_void_p), _I, _I, _I, _I, _I, _P]),
+    "wm2f_mask_loss_rows_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "wm2f_mask_loss_rows_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "wm2f_instance_scores": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_instance_any": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_instance_segmentation": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -41,6 +45,8 @@ SIGNATURES = {
     "wm2f_matcher_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_matcher_cost": (c_int, [_P, _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                   c_float, c_float, c_float, _P]),
+    "wm2f_matcher_cost_levels": (c_int, [POINTER(c_void_p), _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
+                                         _I, _I, _I, c_float, c_float, c_float, _P]),
     "wm2f_bias_act": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_add_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _I, c_int64, c_float, _P]),
     "wm2f_point_sample_fwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),

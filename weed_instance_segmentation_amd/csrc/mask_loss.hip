@@ -1,0 +1,196 @@
+// Point-sampled mask loss, batched over the prediction levels.
+// Replaces, for all 10 levels of a step at once, what transformers 5.15.0 modeling_mask2former.py does per level:
+//   sample_point on the matched prediction maps (:245-274, called from :602-640 and :671-724),
+//   sigmoid_cross_entropy_loss (:308-324) and dice_loss (:278-305) over the sampled points.
+// The level tensors stay where the mask predictor wrote them: the kernels take a table of base pointers
+// (at most 16 levels, passed by value) instead of a stacked copy (10 x 210 MB at config 2).
+//   point_sample_levels_fwd : out[l][m][p] = bilinear(maps[l][index[l][m]], pts[l][m][p])  (or -|.|: the
+//                             uncertainty of :688-690)
+//   point_sample_levels_bwd : scatter of grad_out into the level gradient maps (fp32 atomics; 4 per point)
+//   mask_loss_rows_fwd      : per matched mask r: mean BCE-with-logits over its points, dice = 1 - (2 sum(p t) + 1) /
+//                             (sum p + sum t + 1); row sums kept for the backward
+//   mask_loss_rows_bwd      : d/dlogit of g_bce[r] * bce_mean[r] + g_dice[r] * dice[r]
+// HBM-bound streaming / gather passes over (levels x masks x points) = 1280 x 12544 values; no roofline claim.
+#include "common.h"
+
+namespace wm2f {
+namespace {
+
+constexpr int kMaxLossLevels = 16;
+struct LevelTable {
+  const float* p[kMaxLossLevels];
+};
+struct LevelTableMut {
+  float* p[kMaxLossLevels];
+};
+
+// grid_sample(bilinear, zeros, align_corners=False) at normalised (x, y) in [0, 1] (HF:245-274 maps them to 2 x - 1)
+__device__ __forceinline__ float sample_zeros(const float* __restrict__ img, int H, int W, float lx, float ly) {
+  const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+  const float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+  const float y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  if (!(x > -1.f && x < (float)W && y > -1.f && y < (float)H)) return 0.f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+  const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
+  const float* p = img + (int64_t)y0 * W + x0;
+  float r = 0.f;
+  if (yt && xl) r += p[0] * (fx0 * fy0);
+  if (yt && xr) r += p[1] * (fx1 * fy0);
+  if (yb && xl) r += p[W] * (fx0 * fy1);
+  if (yb && xr) r += p[W + 1] * (fx1 * fy1);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void point_sample_levels_fwd_kernel(LevelTable maps, const float* __restrict__ pts,
+                                                                      const int32_t* __restrict__ index,
+                                                                      float* __restrict__ out, int M, int H, int W, int P,
+                                                                      int neg_abs) {
+  const int p = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, l = blockIdx.z;
+  if (p >= P) return;
+  const int64_t row = (int64_t)l * M + m;
+  const float* pp = pts + (row * P + p) * 2;
+  const float v = sample_zeros(maps.p[l] + (int64_t)index[row] * H * W, H, W, pp[0], pp[1]);
+  out[row * P + p] = neg_abs ? -fabsf(v) : v;
+}
+
+__global__ __launch_bounds__(256) void point_sample_levels_bwd_kernel(const float* __restrict__ grad_out,
+                                                                      const float* __restrict__ pts,
+                                                                      const int32_t* __restrict__ index, LevelTableMut grads,
+                                                                      int M, int H, int W, int P) {
+  const int p = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, l = blockIdx.z;
+  if (p >= P) return;
+  const int64_t row = (int64_t)l * M + m;
+  const float* pp = pts + (row * P + p) * 2;
+  const float go = grad_out[row * P + p];
+  const float x = ((2.f * pp[0] - 1.f + 1.f) * (float)W - 1.f) * 0.5f;
+  const float y = ((2.f * pp[1] - 1.f + 1.f) * (float)H - 1.f) * 0.5f;
+  if (!(x > -1.f && x < (float)W && y > -1.f && y < (float)H)) return;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+  const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
+  float* g = grads.p[l] + (int64_t)index[row] * H * W + (int64_t)y0 * W + x0;
+  if (yt && xl) atomicAdd(g, go * fx0 * fy0);
+  if (yt && xr) atomicAdd(g + 1, go * fx1 * fy0);
+  if (yb && xl) atomicAdd(g + W, go * fx0 * fy1);
+  if (yb && xr) atomicAdd(g + W + 1, go * fx1 * fy1);
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// sums (R, 4): sum of BCE terms, sum p t, sum p, sum t;  bce_mean (R), dice (R)
+__global__ __launch_bounds__(256) void mask_loss_rows_fwd_kernel(const float* __restrict__ logits,
+                                                                 const float* __restrict__ labels, float* __restrict__ sums,
+                                                                 float* __restrict__ bce_mean, float* __restrict__ dice,
+                                                                 int P) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const float *x = logits + r * P, *t = labels + r * P;
+  float sb = 0.f, spt = 0.f, sp = 0.f, st = 0.f;
+  for (int i = threadIdx.x; i < P; i += 256) {
+    const float xi = x[i], ti = t[i];
+    // binary_cross_entropy_with_logits: max(x, 0) - x t + log1p(exp(-|x|))
+    sb += fmaxf(xi, 0.f) - xi * ti + log1pf(__expf(-fabsf(xi)));
+    const float pi = 1.f / (1.f + __expf(-xi));
+    spt += pi * ti;
+    sp += pi;
+    st += ti;
+  }
+  sb = block_sum256(sb, red);
+  spt = block_sum256(spt, red);
+  sp = block_sum256(sp, red);
+  st = block_sum256(st, red);
+  if (threadIdx.x == 0) {
+    sums[r * 4 + 0] = sb;
+    sums[r * 4 + 1] = spt;
+    sums[r * 4 + 2] = sp;
+    sums[r * 4 + 3] = st;
+    bce_mean[r] = sb / (float)P;                              // HF:321-323: mean over points
+    dice[r] = 1.f - (2.f * spt + 1.f) / (sp + st + 1.f);      // HF:299-303
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_loss_rows_bwd_kernel(const float* __restrict__ logits,
+                                                                 const float* __restrict__ labels,
+                                                                 const float* __restrict__ sums,
+                                                                 const float* __restrict__ g_bce, const float* __restrict__ g_dice,
+                                                                 float* __restrict__ grad, int P) {
+  const int64_t r = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float xi = logits[r * P + i], ti = labels[r * P + i];
+  const float pi = 1.f / (1.f + __expf(-xi));
+  const float N = 2.f * sums[r * 4 + 1] + 1.f, Dn = sums[r * 4 + 2] + sums[r * 4 + 3] + 1.f;
+  // d bce_mean / dx = (p - t) / P;   d dice / dp = -(2 t Dn - N) / Dn^2,  dp/dx = p (1 - p)
+  const float gd = -(2.f * ti * Dn - N) / (Dn * Dn) * pi * (1.f - pi);
+  grad[r * P + i] = g_bce[r] * (pi - ti) / (float)P + g_dice[r] * gd;
+}
+
+}  // namespace
+}  // namespace wm2f
+
+using namespace wm2f;
+
+extern "C" int wm2f_point_sample_levels_fwd(const void* const* level_maps, int n_levels, const void* pts, const int32_t* index,
+                                            void* out, int M, int H, int W, int P, int neg_abs, void* stream) {
+  const char* who = "wm2f_point_sample_levels_fwd";
+  WM2F_REQUIRE(level_maps && pts && index && out, "%s: null pointer", who);
+  WM2F_REQUIRE(n_levels > 0 && n_levels <= kMaxLossLevels, "%s: 1..%d levels", who, kMaxLossLevels);
+  WM2F_REQUIRE(M > 0 && M < 65536 && H > 0 && W > 0 && P > 0, "%s: bad size", who);
+  LevelTable tab;
+  for (int l = 0; l < kMaxLossLevels; ++l) tab.p[l] = (const float*)level_maps[l < n_levels ? l : 0];
+  for (int l = 0; l < n_levels; ++l) WM2F_REQUIRE(tab.p[l], "%s: null level pointer", who);
+  hipLaunchKernelGGL(point_sample_levels_fwd_kernel, dim3(ceil_div(P, 256), M, n_levels), dim3(256), 0, (hipStream_t)stream,
+                     tab, (const float*)pts, index, (float*)out, M, H, W, P, neg_abs);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_point_sample_levels_bwd(const void* grad_out, const void* pts, const int32_t* index,
+                                            void* const* level_grads, int n_levels, int M, int H, int W, int P,
+                                            void* stream) {
+  const char* who = "wm2f_point_sample_levels_bwd";
+  WM2F_REQUIRE(grad_out && pts && index && level_grads, "%s: null pointer", who);
+  WM2F_REQUIRE(n_levels > 0 && n_levels <= kMaxLossLevels, "%s: 1..%d levels", who, kMaxLossLevels);
+  WM2F_REQUIRE(M > 0 && M < 65536 && H > 0 && W > 0 && P > 0, "%s: bad size", who);
+  LevelTableMut tab;
+  for (int l = 0; l < kMaxLossLevels; ++l) tab.p[l] = (float*)level_grads[l < n_levels ? l : 0];
+  for (int l = 0; l < n_levels; ++l) WM2F_REQUIRE(tab.p[l], "%s: null level pointer", who);
+  hipLaunchKernelGGL(point_sample_levels_bwd_kernel, dim3(ceil_div(P, 256), M, n_levels), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)grad_out, (const float*)pts, index, tab, M, H, W, P);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_mask_loss_rows_fwd(const void* logits, const void* labels, void* sums, void* bce_mean, void* dice,
+                                       int R, int P, void* stream) {
+  const char* who = "wm2f_mask_loss_rows_fwd";
+  WM2F_REQUIRE(logits && labels && sums && bce_mean && dice, "%s: null pointer", who);
+  WM2F_REQUIRE(R > 0 && P > 0, "%s: non-positive size", who);
+  hipLaunchKernelGGL(mask_loss_rows_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)logits,
+                     (const float*)labels, (float*)sums, (float*)bce_mean, (float*)dice, P);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_mask_loss_rows_bwd(const void* logits, const void* labels, const void* sums, const void* g_bce,
+                                       const void* g_dice, void* grad, int R, int P, void* stream) {
+  const char* who = "wm2f_mask_loss_rows_bwd";
+  WM2F_REQUIRE(logits && labels && sums && g_bce && g_dice && grad, "%s: null pointer", who);
+  WM2F_REQUIRE(R > 0 && R < 65536 && P > 0, "%s: bad size", who);
+  hipLaunchKernelGGL(mask_loss_rows_bwd_kernel, dim3(ceil_div(P, 256), R), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)logits, (const float*)labels, (const float*)sums, (const float*)g_bce,
+                     (const float*)g_dice, (float*)grad, P);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

@@ -100,9 +100,13 @@ constexpr int kQG = 2, kTC = 16, kMaxImg = 64;
 struct MatcherImages {
   int off[kMaxImg + 1];  // target offsets per image
 };
+constexpr int kMaxMatchLevels = 16;
+struct MatcherLevels {  // base pointer of each prediction level's (B, Q, h, w) logits: the levels are NOT stacked
+  const float* p[kMaxMatchLevels];
+};
 
 __global__ __launch_bounds__(256) void matcher_cost_kernel(
-    const float* __restrict__ mask_logits, const float* __restrict__ class_logits, const float* __restrict__ tm,
+    MatcherLevels levels, const float* __restrict__ class_logits, const float* __restrict__ tm,
     const int64_t* __restrict__ tgt_classes, const float* __restrict__ points, float* __restrict__ cost,
     MatcherImages im, int B, int Q, int C1, int h, int w, int P, int Tsum, int Tmax, float w_class, float w_mask,
     float w_dice) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void matcher_cost_kernel(
   const int t_begin = im.off[b], T = im.off[b + 1] - t_begin;
   if (T <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* ml = mask_logits + ((int64_t)lvl * B + b) * Q * h * w;
+  const float* ml = levels.p[lvl] + (int64_t)b * Q * h * w;
   const float* pts = points + ((int64_t)lvl * B + b) * P * 2;
   const float* tml = tm + ((int64_t)lvl * Tsum + t_begin) * P;
   const float* clb = class_logits + ((int64_t)lvl * B + b) * Q * C1;
@@ -223,17 +227,15 @@ extern "C" int64_t wm2f_matcher_workspace(int NL, int B, int Q, int P, int Tsum)
   return (int64_t)NL * Tsum * P * 4;
 }
 
-extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const void* tgt_masks,
-                                 int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes,
-                                 const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1, int h,
-                                 int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask, float w_dice,
-                                 void* stream) {
-  const char* who = "wm2f_matcher_cost";
-  WM2F_REQUIRE(mask_logits && class_logits && tgt_offset && points && cost, "%s: null pointer", who);
+static int matcher_cost_impl(const MatcherLevels& levels, const void* class_logits, const void* tgt_masks,
+                             int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes, const void* points,
+                             void* cost, void* workspace, int NL, int B, int Q, int C1, int h, int w, int Ht, int Wt,
+                             int P, int Tmax, float w_class, float w_mask, float w_dice, void* stream, const char* who) {
+  WM2F_REQUIRE(class_logits && tgt_offset && points && cost, "%s: null pointer", who);
   WM2F_REQUIRE(NL > 0 && B > 0 && Q > 0 && C1 > 0 && h > 0 && w > 0 && Ht > 0 && Wt > 0 && P > 0,
                "%s: non-positive size", who);
   WM2F_REQUIRE(tgt_dtype == 0 || tgt_dtype == 1, "%s: tgt_dtype must be 0 (fp32) or 1 (uint8)", who);
-  WM2F_REQUIRE(NL <= 65535, "%s: too many levels", who);
+  WM2F_REQUIRE(NL <= kMaxMatchLevels, "%s: at most %d levels per call", who, kMaxMatchLevels);
   const int Tsum = tgt_offset[B];
   WM2F_REQUIRE(tgt_offset[0] == 0 && Tsum >= 0, "%s: bad tgt_offset", who);
   if (Tsum == 0) return WM2F_OK;
@@ -262,11 +264,41 @@ extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logi
                          pts_stride_lvl, tm_stride_lvl);
   }
   dim3 gb(ceil_div(Q, kQG), NL, B);
-  hipLaunchKernelGGL(matcher_cost_kernel, gb, dim3(256), 0, st, (const float*)mask_logits,
+  hipLaunchKernelGGL(matcher_cost_kernel, gb, dim3(256), 0, st, levels,
                      (const float*)class_logits, (const float*)tm, (const int64_t*)tgt_classes,
                      (const float*)points, (float*)cost, im, B, Q, C1, h, w, P, Tsum, Tmax, w_class, w_mask, w_dice);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
+}
+
+extern "C" int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const void* tgt_masks,
+                                 int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes,
+                                 const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1, int h,
+                                 int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                                 void* stream) {
+  const char* who = "wm2f_matcher_cost";
+  WM2F_REQUIRE(mask_logits, "%s: null pointer", who);
+  WM2F_REQUIRE(NL > 0 && NL <= kMaxMatchLevels && B > 0 && Q > 0 && h > 0 && w > 0, "%s: bad size", who);
+  MatcherLevels lv;
+  for (int l = 0; l < kMaxMatchLevels; ++l)
+    lv.p[l] = (const float*)mask_logits + (int64_t)(l < NL ? l : 0) * B * Q * h * w;
+  return matcher_cost_impl(lv, class_logits, tgt_masks, tgt_dtype, tgt_offset, tgt_classes, points, cost, workspace, NL, B,
+                           Q, C1, h, w, Ht, Wt, P, Tmax, w_class, w_mask, w_dice, stream, who);
+}
+
+extern "C" int wm2f_matcher_cost_levels(const void* const* mask_levels, const void* class_logits, const void* tgt_masks,
+                                        int tgt_dtype, const int32_t* tgt_offset, const void* tgt_classes,
+                                        const void* points, void* cost, void* workspace, int NL, int B, int Q, int C1,
+                                        int h, int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask,
+                                        float w_dice, void* stream) {
+  const char* who = "wm2f_matcher_cost_levels";
+  WM2F_REQUIRE(mask_levels, "%s: null pointer", who);
+  WM2F_REQUIRE(NL > 0 && NL <= kMaxMatchLevels, "%s: 1..%d levels", who, kMaxMatchLevels);
+  MatcherLevels lv;
+  for (int l = 0; l < kMaxMatchLevels; ++l) lv.p[l] = (const float*)mask_levels[l < NL ? l : 0];
+  for (int l = 0; l < NL; ++l) WM2F_REQUIRE(lv.p[l], "%s: null level pointer", who);
+  return matcher_cost_impl(lv, class_logits, tgt_masks, tgt_dtype, tgt_offset, tgt_classes, points, cost, workspace, NL, B,
+                           Q, C1, h, w, Ht, Wt, P, Tmax, w_class, w_mask, w_dice, stream, who);
 }
 
 extern "C" int wm2f_point_sample_fwd(const void* feat, int feat_dtype, const void* pts, const void* map_index,

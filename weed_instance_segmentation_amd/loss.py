@@ -81,6 +81,7 @@ class Mask2FormerLoss(nn.Module):
         self.num_points = config.train_num_points
         self.oversample_ratio = config.oversample_ratio
         self.importance_sample_ratio = config.importance_sample_ratio
+        self.batched_levels = True  # loss_masks_all_levels; False = one pass per level (kept for A/B and tests)
         self.cost_class, self.cost_mask, self.cost_dice = config.class_weight, config.mask_weight, config.dice_weight
         self.world_size_fn = None  # set by parallel.DataParallelEngine: all-reduces num_masks (HF:781-794)
 
@@ -92,10 +93,10 @@ class Mask2FormerLoss(nn.Module):
         if sum(counts) == 0:
             e = torch.zeros(0, dtype=torch.int64)
             return [[(e, e) for _ in range(B)] for _ in range(NL)]
-        ml = torch.stack([m.detach() for m in all_masks]) if NL > 1 else all_masks[0].detach()[None]
+        ml = [m.detach().float() for m in all_masks]  # used where they are: a stacked copy is 10 x 210 MB at config 2
         cl = torch.stack([c.detach() for c in all_classes]) if NL > 1 else all_classes[0].detach()[None]
-        cost = ops.matcher_cost(ml.float(), cl.float(), tgt, counts, cls, points, self.cost_class, self.cost_mask,
-                                self.cost_dice)
+        cost = ops.matcher_cost(ml if NL <= 16 else torch.stack(ml), cl.float(), tgt, counts, cls, points, self.cost_class,
+                                self.cost_mask, self.cost_dice)
         cost = cost.cpu().numpy()  # the ONE device->host sync of the step
         indices = []
         for l in range(NL):
@@ -124,6 +125,22 @@ class Mask2FormerLoss(nn.Module):
         target = torch.full((B, Q), self.num_labels, dtype=torch.int64, device=dev)
         target[bi, si] = cls[ti]
         return F.cross_entropy(classes.transpose(1, 2), target, weight=self.empty_weight)
+
+    def loss_labels_all_levels(self, all_classes, cls, offsets, indices, order):
+        """`loss_labels` (HF:546-578) for every level of `order` with one cross-entropy call: (len(order),) tensor of the
+        weighted means sum(w_i * nll_i) / sum(w_i) that nn.CrossEntropyLoss(weight=...) returns per level."""
+        B, Q, C1 = all_classes[0].shape
+        dev = all_classes[0].device
+        logits = torch.stack([all_classes[lvl] for lvl in order])  # (NL, B, Q, C1): tiny
+        li = torch.cat([torch.full((sum(int(s.numel()) for s, _ in indices[lvl]),), n, dtype=torch.int64) for n, lvl in enumerate(order)])
+        bi = torch.cat([torch.full_like(s, i) for lvl in order for i, (s, _) in enumerate(indices[lvl])])
+        si = torch.cat([s for lvl in order for s, _ in indices[lvl]])
+        ti = torch.cat([t + offsets[i] for lvl in order for i, (_, t) in enumerate(indices[lvl])])
+        target = torch.full((len(order), B, Q), self.num_labels, dtype=torch.int64, device=dev)
+        target[li.to(dev), bi.to(dev), si.to(dev)] = cls[ti.to(dev)]
+        nll = F.cross_entropy(logits.reshape(-1, C1).float(), target.reshape(-1), weight=self.empty_weight, reduction="none")
+        wts = self.empty_weight[target.reshape(-1)]
+        return nll.view(len(order), -1).sum(1) / wts.view(len(order), -1).sum(1)
 
     def loss_masks(self, masks, tgt, offsets, indices, num_masks, level, provider):
         """HF:580-640 with the uncertainty sampling of HF:671-724.  Matched prediction and target
@@ -157,6 +174,38 @@ class Mask2FormerLoss(nn.Module):
         loss_dice = (1 - (num + 1) / (den + 1)).sum() / num_masks  # HF:278-305
         return loss_mask, loss_dice
 
+    def loss_masks_all_levels(self, all_masks, tgt, offsets, indices, num_masks, order, provider):
+        """`loss_masks` for every level of `order` in one pass: the level tensors are sampled where
+        they are (pointer table), the top-k, the target sampling and the BCE / dice reductions run once over
+        (levels x matched masks) rows.  Returns two (len(order),) tensors: loss_mask, loss_dice per level."""
+        dev = all_masks[0].device
+        B, Q, h, w = all_masks[0].shape
+        NL, P = len(order), self.num_points
+        pred_idx = torch.stack([torch.cat([s + i * Q for i, (s, _) in enumerate(indices[lvl])]) for lvl in order])
+        tgt_idx = torch.stack([torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices[lvl])]) for lvl in order])
+        M = int(pred_idx.shape[1])
+        if M == 0:
+            z = torch.stack([all_masks[lvl].sum() * 0.0 for lvl in order])
+            return z, z
+        pred_idx = pred_idx.to(device=dev, dtype=torch.int32)
+        tgt_idx = tgt_idx.to(device=dev, dtype=torch.int32)
+        maps = [all_masks[lvl].reshape(B * Q, h, w).float() for lvl in order]
+        n_over = int(P * self.oversample_ratio)
+        n_unc = int(self.importance_sample_ratio * P)
+        with torch.no_grad():
+            pc = torch.stack([provider.oversample_points(lvl, M, n_over) for lvl in order])  # (NL, M, n_over, 2)
+            unc = ops.point_sample_levels([m.detach() for m in maps], pc, pred_idx, neg_abs=True)
+            idx = torch.topk(unc.view(NL * M, n_over), k=n_unc, dim=1)[1]
+            pts = torch.gather(pc.view(NL * M, n_over, 2), 1, idx[..., None].expand(-1, -1, 2))
+            if P - n_unc > 0:
+                rnd = torch.stack([provider.random_points(lvl, M, P - n_unc) for lvl in order]).view(NL * M, P - n_unc, 2)
+                pts = torch.cat([pts, rnd], 1)
+            pts = pts.contiguous()
+            point_labels = ops.point_sample(tgt, pts, tgt_idx.view(-1))
+        point_logits = ops.point_sample_levels(maps, pts.view(NL, M, P, 2), pred_idx)
+        bce, dice = ops.mask_loss_rows(point_logits.view(NL * M, P), point_labels)
+        return bce.view(NL, M).sum(1) / num_masks, dice.view(NL, M).sum(1) / num_masks
+
     def forward(self, all_masks, all_classes, mask_labels, class_labels, point_provider=None):
         """all_masks / all_classes: per-level lists in decoder order, LAST = final prediction.
         Returns (weighted loss dict with the dependency's key names, indices of the final level)."""
@@ -180,9 +229,17 @@ class Mask2FormerLoss(nn.Module):
         num_masks = self._num_masks(counts, dev)
         losses = {}
         order = [NL - 1] + list(range(NL - 1))  # HF:762-777: final level first, then aux 0..n-2
+        same_m = len({sum(int(s.numel()) for s, _ in indices[lvl]) for lvl in order}) == 1
+        batched = self.batched_levels and same_m and NL <= 16
+        if batched:
+            lm_all, ld_all = self.loss_masks_all_levels(all_masks, tgt, offsets, indices, num_masks, order, provider)
+            lc_all = self.loss_labels_all_levels(all_classes, cls, offsets, indices, order)
         for n, lvl in enumerate(order):
-            lm, ld = self.loss_masks(all_masks[lvl], tgt, offsets, indices[lvl], num_masks, lvl, provider)
-            lc = self.loss_labels(all_classes[lvl], cls, offsets, indices[lvl])
+            if batched:
+                lm, ld, lc = lm_all[n], ld_all[n], lc_all[n]
+            else:
+                lm, ld = self.loss_masks(all_masks[lvl], tgt, offsets, indices[lvl], num_masks, lvl, provider)
+                lc = self.loss_labels(all_classes[lvl], cls, offsets, indices[lvl])
             suffix = "" if n == 0 else f"_{lvl}"
             losses["loss_mask" + suffix] = lm * self.weight_dict["loss_mask"]
             losses["loss_dice" + suffix] = ld * self.weight_dict["loss_dice"]

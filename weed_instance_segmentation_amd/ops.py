@@ -273,11 +273,20 @@ def masked_xattn(q, k, v, mask, row_open, heads: int) -> torch.Tensor:
 def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, points, w_class, w_mask, w_dice):
     """K4 -- all cost matrices of a step in one go (HF:444-472), no sync.
 
-    mask_logits (NL,B,Q,h,w); class_logits (NL,B,Q,C1); tgt_masks (sum T, Ht, Wt) fp32 or uint8;
+    mask_logits (NL,B,Q,h,w) or a list of NL (B,Q,h,w) tensors (not stacked); class_logits (NL,B,Q,C1); tgt_masks (sum T, Ht, Wt) fp32 or uint8;
     tgt_counts: python list of T_i; tgt_classes (sum T,) int64; points (NL,B,P,2).
     Returns cost (NL,B,Q,Tmax) fp32 on the device; columns >= T_i are zero."""
-    mask_logits, class_logits, points = _req(mask_logits, "mask_logits"), _req(class_logits, "class_logits"), _req(points, "points")
-    NL, B, Q, h, w = mask_logits.shape
+    class_logits, points = _req(class_logits, "class_logits"), _req(points, "points")
+    levels = None
+    if isinstance(mask_logits, (list, tuple)):  # one (B,Q,h,w) tensor per level, used where it is
+        levels = [_req(m, "mask level") for m in mask_logits]
+        mask_logits = levels[0]
+        NL, (B, Q, h, w) = len(levels), mask_logits.shape
+        if any(m.shape != mask_logits.shape for m in levels):
+            raise ValueError("matcher_cost: level tensors of different shapes")
+    else:
+        mask_logits = _req(mask_logits, "mask_logits")
+        NL, B, Q, h, w = mask_logits.shape
     C1 = class_logits.shape[-1]
     P = points.shape[2]
     if tgt_masks.dtype == torch.bool:
@@ -296,9 +305,17 @@ def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, 
     lib = load()
     ws = torch.empty(max(int(lib.wm2f_matcher_workspace(NL, B, Q, P, Tsum)), 4), device=mask_logits.device, dtype=torch.uint8)
     with torch.cuda.device(mask_logits.device):
-        check(lib.wm2f_matcher_cost(_p(mask_logits), _p(class_logits), _p(tgt_masks), tdt, host_i32(offs), _p(tgt_classes),
-                                    _p(points), _p(cost), _p(ws), NL, B, Q, C1, h, w, Ht, Wt, P, Tmax, float(w_class),
-                                    float(w_mask), float(w_dice), _stream(mask_logits)), "wm2f_matcher_cost")
+        if levels is not None:
+            tab = (ctypes.c_void_p * NL)(*[m.data_ptr() for m in levels])
+            check(_timed("matcher_cost", mask_logits, lambda: lib.wm2f_matcher_cost_levels(
+                tab, _p(class_logits), _p(tgt_masks), tdt, host_i32(offs), _p(tgt_classes), _p(points), _p(cost), _p(ws), NL,
+                B, Q, C1, h, w, Ht, Wt, P, Tmax, float(w_class), float(w_mask), float(w_dice), _stream(mask_logits))),
+                "wm2f_matcher_cost_levels")
+        else:
+            check(_timed("matcher_cost", mask_logits, lambda: lib.wm2f_matcher_cost(
+                _p(mask_logits), _p(class_logits), _p(tgt_masks), tdt, host_i32(offs), _p(tgt_classes), _p(points), _p(cost),
+                _p(ws), NL, B, Q, C1, h, w, Ht, Wt, P, Tmax, float(w_class), float(w_mask), float(w_dice),
+                _stream(mask_logits))), "wm2f_matcher_cost")
     return cost
 
 
@@ -436,3 +453,76 @@ def instance_maps(image_logits, kept_q, n, size):
         check(load().wm2f_instance_maps(_p(image_logits), _p(kept_q), int(n), _p(maps), h, w, _GRID[0], _GRID[1],
                                         int(size[0]), int(size[1]), _stream(image_logits)), "wm2f_instance_maps")
     return maps
+
+
+# ------------------------------------------------------ point-sampled mask loss over all levels
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _PointSampleLevels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, index, neg_abs, *maps):
+        maps = [_req(m, "level map") for m in maps]
+        pts, index = _req(pts, "pts"), _req(index, "index", torch.int32)
+        NL, M, P = pts.shape[:3]
+        N, H, W = maps[0].shape
+        if len(maps) != NL or index.shape != (NL, M) or any(m.shape != (N, H, W) for m in maps):
+            raise ValueError("point_sample_levels: one (N,H,W) map per level, pts (NL,M,P,2), index (NL,M)")
+        out = torch.empty(NL, M, P, device=pts.device, dtype=torch.float32)
+        with torch.cuda.device(pts.device):
+            check(_timed("point_sample_levels_fwd", pts, lambda: load().wm2f_point_sample_levels_fwd(
+                _ptr_table(maps), NL, _p(pts), _p(index), _p(out), M, H, W, P, 1 if neg_abs else 0, _stream(pts))),
+                "wm2f_point_sample_levels_fwd")
+        ctx.save_for_backward(pts, index)
+        ctx.shape = (NL, N, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pts, index = ctx.saved_tensors
+        NL, N, H, W = ctx.shape
+        grad_out = _req(grad_out, "grad_out")
+        grads = [torch.zeros(N, H, W, device=pts.device, dtype=torch.float32) for _ in range(NL)]
+        with torch.cuda.device(pts.device):
+            check(_timed("point_sample_levels_bwd", pts, lambda: load().wm2f_point_sample_levels_bwd(
+                _p(grad_out), _p(pts), _p(index), _ptr_table(grads), NL, pts.shape[1], H, W, pts.shape[2], _stream(pts))),
+                "wm2f_point_sample_levels_bwd")
+        return (None, None, None, *grads)
+
+
+def point_sample_levels(maps, pts: torch.Tensor, index: torch.Tensor, neg_abs: bool = False) -> torch.Tensor:
+    """sample_point (HF:245-274) on one (N,H,W) map tensor PER LEVEL without stacking them: pts (NL,M,P,2) in [0,1]
+    (x,y), index (NL,M) int32 = which map of its level row m samples -> (NL,M,P).  neg_abs: -|value| (HF:688-690)."""
+    return _PointSampleLevels.apply(pts, index, bool(neg_abs), *maps)
+
+
+class _MaskLossRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits, labels = _req(logits, "logits"), _req(labels, "labels")
+        R, P = logits.shape
+        sums = torch.empty(R, 4, device=logits.device, dtype=torch.float32)
+        bce, dice = torch.empty(R, device=logits.device), torch.empty(R, device=logits.device)
+        with torch.cuda.device(logits.device):
+            check(_timed("mask_loss_rows_fwd", logits, lambda: load().wm2f_mask_loss_rows_fwd(
+                _p(logits), _p(labels), _p(sums), _p(bce), _p(dice), R, P, _stream(logits))), "wm2f_mask_loss_rows_fwd")
+        ctx.save_for_backward(logits, labels, sums)
+        return bce, dice
+
+    @staticmethod
+    def backward(ctx, g_bce, g_dice):
+        logits, labels, sums = ctx.saved_tensors
+        R, P = logits.shape
+        g_bce, g_dice = _req(g_bce, "g_bce"), _req(g_dice, "g_dice")
+        grad = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            check(_timed("mask_loss_rows_bwd", logits, lambda: load().wm2f_mask_loss_rows_bwd(
+                _p(logits), _p(labels), _p(sums), _p(g_bce), _p(g_dice), _p(grad), R, P, _stream(logits))),
+                "wm2f_mask_loss_rows_bwd")
+        return grad, None
+
+
+def mask_loss_rows(logits: torch.Tensor, labels: torch.Tensor):
+    """Per matched mask (row): (mean BCE-with-logits over its points HF:308-324, dice HF:278-305), differentiable in logits."""
+    return _MaskLossRows.apply(logits, labels)
