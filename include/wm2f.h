@@ -237,6 +237,15 @@ int wm2f_instance_segmentation(const void* mask_logits, const int32_t* kept_q, c
 int wm2f_instance_maps(const void* image_logits, const int32_t* kept_q, int n, void* maps, int h, int w, int gh,
                        int gw, int Ho, int Wo, void* stream);
 
+/* ---- label expansion on device ------------------------------------------
+ * The tensor work of convert_segmentation_map_to_binary_masks (image_processing_mask2former.py:227-259,
+ * image_processing_pil_mask2former.py:81-114), so that a sample can travel as its (H, W) instance-id map instead of
+ * the float (T, H, W) mask stack the reference stores (datasets/dataset_utils.py:56-70).
+ *   label_map (n_pixels) int32 DEVICE, n_pixels % 4 == 0; ids (T) int32 DEVICE (ascending unique ids, ignore
+ *   index removed); masks (T, n_pixels) uint8: masks[t][i] = (label_map[i] == ids[t]). */
+int wm2f_labelmap_to_masks(const int32_t* label_map, const int32_t* ids, uint8_t* masks, int64_t n_pixels, int T,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

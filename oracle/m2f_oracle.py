@@ -495,3 +495,23 @@ def post_process_instance_segmentation(class_queries_logits, masks_queries_logit
             seg = torch.stack(maps, 0)
         results.append({"segmentation": seg, "segments_info": segments})
     return results
+
+
+# --------------------------------------------------------------------------------------------------
+# Label expansion: restates convert_segmentation_map_to_binary_masks,
+# image_processing_pil_mask2former.py:81-114 (same algorithm as image_processing_mask2former.py:227-259), as the
+# reference uses it (datasets/pheno_bench/dataset.py:117-123: ignore_index=255, no label reduction).
+def convert_segmentation_map_to_binary_masks(segmentation_map, instance_id_to_semantic_id=None, ignore_index=None):
+    seg = torch.as_tensor(segmentation_map)
+    all_labels = torch.unique(seg)
+    if ignore_index is not None:
+        all_labels = all_labels[all_labels != ignore_index]
+    if len(all_labels):
+        masks = torch.stack([seg == i for i in all_labels], 0)
+    else:
+        masks = torch.zeros((0, *seg.shape))
+    if instance_id_to_semantic_id is not None:
+        labels = torch.tensor([instance_id_to_semantic_id[int(i)] for i in all_labels], dtype=torch.int64)
+    else:
+        labels = all_labels.long()
+    return masks.float(), labels

@@ -404,6 +404,24 @@ def gen_postprocess():
     print("kept per image:", [len(x) for x in info["mixed"]["segments_info"]])
 
 
+def gen_labelmap():
+    """convert_segmentation_map_to_binary_masks of the dependency on a synthetic instance map in the reference's
+    format (datasets/pheno_bench/dataset.py:85-116: int32 map, 255 = background/ignore, ids 1..N skipping 255)."""
+    from transformers.models.mask2former.image_processing_pil_mask2former import convert_segmentation_map_to_binary_masks
+    rng = np.random.default_rng(7)
+    H, W = 48, 64
+    inst = np.full((H, W), 255, dtype=np.int32)
+    id2sem = {}
+    for iid in [1, 2, 3, 5, 8, 254, 256, 300]:
+        hh, ww = rng.integers(4, 16, 2)
+        y0, x0 = rng.integers(0, H - hh), rng.integers(0, W - ww)
+        inst[y0:y0 + hh, x0:x0 + ww] = iid
+        id2sem[iid] = int(rng.integers(1, 5))
+    masks, labels = convert_segmentation_map_to_binary_masks(inst, id2sem, ignore_index=255)
+    save("labelmap_masks.npz", instance_map=inst, masks=masks.astype(np.uint8), labels=labels,
+         id2sem_json=np.asarray(json.dumps({str(k): v for k, v in id2sem.items()})))
+
+
 def gen_state_keys():
     from transformers import SwinConfig
     res = {}
@@ -423,8 +441,8 @@ def gen_state_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["k1", "a2", "k2", "k3", "k4", "full", "keys", "swin", "post"]
+    which = sys.argv[1:] or ["k1", "a2", "k2", "k3", "k4", "full", "keys", "swin", "post", "labelmap"]
     torch.set_num_threads(8)
     for w in which:
         {"k1": gen_k1, "a2": gen_a2, "k2": gen_k2, "k3": gen_k3, "k4": gen_k4, "full": gen_full,
-         "keys": gen_state_keys, "swin": gen_swin, "post": gen_postprocess}[w]()
+         "keys": gen_state_keys, "swin": gen_swin, "post": gen_postprocess, "labelmap": gen_labelmap}[w]()

@@ -213,3 +213,45 @@ extern "C" int wm2f_instance_maps(const void* image_logits, const int32_t* kept_
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Label expansion on device: convert_segmentation_map_to_binary_masks
+// (image_processing_mask2former.py:227-259 / image_processing_pil_mask2former.py:81-114) writes one binary mask per
+// instance id present in the map.  The reference stores them as float (T, H, W) inside every .pt sample
+// (datasets/dataset_utils.py:56-70) -- 64 MB per 1024 x 1024 image with 16 instances, the largest host-to-device
+// copy of a step.  Shipping the (H, W) id map and expanding here moves 4 MB instead (1 MB as uint8 maps).
+//   out[t][i] = (map[i] == ids[t]) as uint8; one pass over the map, T coalesced output streams.
+namespace wm2f {
+namespace {
+__global__ __launch_bounds__(256) void labelmap_to_masks_kernel(const int32_t* __restrict__ map,
+                                                                const int32_t* __restrict__ ids, uint8_t* __restrict__ out,
+                                                                int64_t n, int T) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = i + k < n ? map[i + k] : INT32_MIN;
+  for (int t = 0; t < T; ++t) {
+    const int id = ids[t];
+    if (i + 3 < n) {
+      const uint32_t w = (uint32_t)(v[0] == id) | ((uint32_t)(v[1] == id) << 8) | ((uint32_t)(v[2] == id) << 16) |
+                         ((uint32_t)(v[3] == id) << 24);
+      *reinterpret_cast<uint32_t*>(out + (int64_t)t * n + i) = w;  // n % 4 == 0 is required for this store
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) out[(int64_t)t * n + i + k] = v[k] == id;
+    }
+  }
+}
+}  // namespace
+}  // namespace wm2f
+
+extern "C" int wm2f_labelmap_to_masks(const int32_t* label_map, const int32_t* ids, uint8_t* masks, int64_t n_pixels, int T,
+                                      void* stream) {
+  const char* who = "wm2f_labelmap_to_masks";
+  WM2F_REQUIRE(label_map && ids && masks, "%s: null pointer", who);
+  WM2F_REQUIRE(n_pixels > 0 && n_pixels % 4 == 0 && T > 0, "%s: need T > 0 and a pixel count divisible by 4", who);
+  hipLaunchKernelGGL(labelmap_to_masks_kernel, dim3((unsigned)ceil_div64(n_pixels, 1024)), dim3(256), 0, (hipStream_t)stream,
+                     label_map, ids, masks, n_pixels, T);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

@@ -526,3 +526,20 @@ class _MaskLossRows(torch.autograd.Function):
 def mask_loss_rows(logits: torch.Tensor, labels: torch.Tensor):
     """Per matched mask (row): (mean BCE-with-logits over its points HF:308-324, dice HF:278-305), differentiable in logits."""
     return _MaskLossRows.apply(logits, labels)
+
+
+# ------------------------------------------------------------------------- label expansion (SURVEY 8f rank 3)
+def labelmap_to_masks(label_map: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """(H, W) int32 id map, (T,) int32 ids -> (T, H, W) uint8 masks `label_map == ids[t]` on the device."""
+    label_map, ids = _req(label_map, "label_map", torch.int32), _req(ids, "ids", torch.int32)
+    H, W = label_map.shape
+    T = int(ids.shape[0])
+    out = torch.empty(T, H, W, device=label_map.device, dtype=torch.uint8)
+    if T == 0:
+        return out
+    if (H * W) % 4:
+        raise ValueError("labelmap_to_masks: H * W must be divisible by 4")
+    with torch.cuda.device(label_map.device):
+        check(load().wm2f_labelmap_to_masks(_p(label_map), _p(ids), _p(out), H * W, T, _stream(label_map)),
+              "wm2f_labelmap_to_masks")
+    return out
