@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--amp", choices=["off", "bf16"], default="off",
+                    help="bf16: run the step under torch.autocast(bfloat16) (BASELINE configs 3-5); the wm2f kernels keep fp32 arithmetic")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +114,7 @@ def main():
         model.eval()
 
         def step():
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.amp == "bf16"):
                 return model(pixel_values=x)
     else:
         from weed_instance_segmentation_amd.parallel import DataParallelEngine
@@ -121,7 +123,10 @@ def main():
         engine = DataParallelEngine(model, lr=5e-5)
 
         def step():
-            return engine.train_step(x, ml, cl)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.amp == "bf16"):
+                out = model(pixel_values=x, mask_labels=ml, class_labels=cl)
+            engine.backward_and_step(out.loss)
+            return out.loss.detach()
 
     for _ in range(a.warmup):
         step()
@@ -153,7 +158,7 @@ def main():
                       + ("fp32 forward-only)" if a.mode == "fwd" else "full train step)"),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (randn pixels, random-init weights seed 0)",
+            "vs_baseline": None, "dtype": "f32" if a.amp == "off" else "bf16 autocast (stock ops bf16, wm2f kernels f32)", "data": "synthetic (randn pixels, random-init weights seed 0)",
             "config": {"workload": f"BASELINE.json configs[1]: synthetic {S}x{S} 3-class, ResNet-50 Mask2Former, "
                                    f"100 queries, fp32 {'forward-only' if a.mode == 'fwd' else 'train step'}, "
                                    f"bs={B} per GPU", "global_batch": world * B, "image_size": S,

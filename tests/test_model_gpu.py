@@ -170,3 +170,46 @@ def test_forward_dim256_fused_inference_paths():
     for out in (out_ng, out_g):
         err = (out - ref).abs().max().item() / ref.abs().max().item()
         assert err < 1e-3, err
+
+
+def test_bf16_autocast_forward_and_train_step(tiny):
+    """BASELINE configs 3-5 run under bf16 autocast.  Stock ops follow PyTorch's autocast policy; the wm2f kernels take
+    the fp32 policy (inputs cast to fp32, as grid_sample / softmax get in the dependency).  Checked against the fp32
+    run and against the CPU oracle executed under the same autocast (bf16 rounding differs per implementation: the
+    bounds are a few bf16 ulps of the logit range)."""
+    from weed_instance_segmentation_amd.loss import ReplayPointProvider
+    g, cfg, model, sd = tiny
+    x = T(g["pixel_values"]).cuda()
+    with torch.no_grad():
+        ref32 = model(pixel_values=x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(pixel_values=x)
+    scale = ref32.masks_queries_logits.abs().max().item()
+    err = (out.masks_queries_logits.float() - ref32.masks_queries_logits).abs().max().item() / scale
+    assert err < 6e-2, err
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        o = O.forward(sd, cfg.to_dict(), T(g["pixel_values"]))
+    # the reference arithmetic under the same autocast is itself this far from fp32; ours must not be further
+    err_o = (o["masks_queries_logits"].float() - ref32.masks_queries_logits.cpu()).abs().max().item() / scale
+    assert err < 1.5 * err_o + 1e-2, (err, err_o)
+    # train step under autocast: finite loss close to the fp32 loss, gradients reach the first backbone layer
+    B = x.shape[0]
+    ml, cl = _labels(g, B)
+    n_layers = cfg.decoder_layers - 1
+    draws = [T(g[f"draw_{i}"]) for i in range(int(g["n_draws"]))][n_layers:]
+    model.train()
+    try:
+        losses = []
+        for amp in (False, True):
+            model.zero_grad(set_to_none=True)
+            prov = ReplayPointProvider(draws, cfg.decoder_layers, B, "cuda")
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                res = model(pixel_values=x, mask_labels=ml, class_labels=cl, point_provider=prov)
+            res.loss.backward()
+            losses.append(res.loss.item())
+            gsum = sum(p.grad.abs().sum().item() for p in model.parameters() if p.grad is not None)
+            assert np.isfinite(gsum) and gsum > 0
+        assert abs(losses[1] - losses[0]) / abs(losses[0]) < 5e-2, losses
+    finally:
+        model.eval()
+        model.zero_grad(set_to_none=True)

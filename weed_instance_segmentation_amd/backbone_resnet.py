@@ -16,7 +16,8 @@ from . import ops
 
 def _fused_ok(x: torch.Tensor) -> bool:
     """Inference on the GPU with a float4-friendly map: use the fused bias(+residual)+ReLU pass."""
-    return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and (x.shape[-1] * x.shape[-2]) % 4 == 0
+    return ((not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
+            and (x.shape[-1] * x.shape[-2]) % 4 == 0)
 
 
 def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d, cache: dict):

@@ -145,7 +145,8 @@ class PixelDecoderEncoderLayer(nn.Module):
 
     def forward(self, hidden, pos, ref, level_hw, hp=None):
         """Returns (hidden, hidden + pos or None).  pos is (S, C), shared by the batch."""
-        if not torch.is_grad_enabled() and self.dropout == 0.0 and hidden.shape[-1] == 256:
+        if (not torch.is_grad_enabled() and self.dropout == 0.0 and hidden.shape[-1] == 256
+                and hidden.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")):
             # inference: residual + LayerNorm fused (and the next layer's hidden + pos with the second one);
             # bias + ReLU in the fc1 GEMM epilogue
             B_, S_, C_ = hidden.shape

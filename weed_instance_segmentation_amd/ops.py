@@ -58,6 +58,19 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+# Mixed precision (BASELINE configs 3-5 run under bf16 autocast): the kernels compute in fp32, so under
+# `torch.autocast` their inputs are cast to fp32 and autocast is switched off inside -- the policy PyTorch itself
+# applies to grid_sample / softmax / layer_norm, which is what the dependency's K1 runs through.  Native bf16
+# storage for K1-K3 is a later round's work.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def _f32(t):
+    """fp32 view of a half-precision tensor for the entry points without autograd (inference, matcher)."""
+    return t.float() if isinstance(t, torch.Tensor) and t.dtype in (torch.bfloat16, torch.float16) else t
+
+
 def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
@@ -71,6 +84,7 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------- K1
 class _MSDeformAttn(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, value, loc, attn_w, level_hw):
         value, loc, attn_w = _req(value, "value"), _req(loc, "loc"), _req(attn_w, "attn_w")
         B, S, H, D = value.shape
@@ -89,6 +103,7 @@ class _MSDeformAttn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         value, loc, attn_w = ctx.saved_tensors
         grad_out = _req(grad_out, "grad_out")
@@ -118,7 +133,8 @@ def ms_deform_attn_fused(value: torch.Tensor, level_hw, offsets: torch.Tensor, l
     offsets (B,Q,heads,L,P,2) raw, logits (B,Q,heads,L*P) raw, ref (Q,L,2)."""
     if torch.is_grad_enabled() and any(t.requires_grad for t in (value, offsets, logits)):
         raise RuntimeError("ms_deform_attn_fused has no backward; use ms_deform_attn when training")
-    value, offsets, logits, ref = _req(value, "value"), _req(offsets, "offsets"), _req(logits, "logits"), _req(ref, "ref")
+    value, offsets, logits, ref = (_req(_f32(value), "value"), _req(_f32(offsets), "offsets"), _req(_f32(logits), "logits"),
+                                   _req(_f32(ref), "ref"))
     B, S, H, D = value.shape
     _, Q, _, L, P, _ = offsets.shape
     if logits.shape != (B, Q, H, L * P) or ref.shape != (Q, L, 2):
@@ -137,7 +153,7 @@ def ms_deform_attn_fused_packed(value, level_hw, packed, ref, heads: int, L: int
     Falls back to the two-array fused kernel (after splitting) where the LDS-window kernel does not apply."""
     if torch.is_grad_enabled() and (value.requires_grad or packed.requires_grad):
         raise RuntimeError("ms_deform_attn_fused_packed has no backward; use ms_deform_attn when training")
-    value, packed = _req(value, "value"), _req(packed, "packed")
+    value, packed, ref = _req(_f32(value), "value"), _req(_f32(packed), "packed"), _f32(ref)
     B, S, H, D = value.shape
     Q = packed.shape[1]
     if H != heads or packed.shape != (B, Q, heads * L * P * 3):
@@ -176,6 +192,7 @@ def ms_deform_attn_variant(value, level_hw, a, b, ref=None, fused=False, variant
 # ----------------------------------------------------------------------------------------- K3
 class _MaskEinsum(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, emb, pix):
         emb, pix = _req(emb, "emb"), _req(pix, "pix")
         B, Q, C = emb.shape
@@ -190,6 +207,7 @@ class _MaskEinsum(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         # Two plain batched GEMMs (library GEMM: rocBLAS / hipBLASLt through torch.bmm).
         emb, pix = ctx.saved_tensors
@@ -207,7 +225,7 @@ def mask_einsum(emb: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
 
 def attn_mask_build(logits: torch.Tensor, size: Sequence[int]):
     """HF:2048-2054 + HF:1912-1914: (mask (B,Q,Hn*Wn) uint8 1=blocked, row_open (B,Q) int32).  No grad."""
-    logits = _req(logits.detach(), "logits")
+    logits = _req(_f32(logits.detach()), "logits")
     B, Q, H, W = logits.shape
     Hn, Wn = int(size[0]), int(size[1])
     mask = torch.empty(B, Q, Hn * Wn, device=logits.device, dtype=torch.uint8)
@@ -221,6 +239,7 @@ def attn_mask_build(logits: torch.Tensor, size: Sequence[int]):
 # ----------------------------------------------------------------------------------------- K2
 class _MaskedXAttn(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q, k, v, mask, row_open, heads):
         q, k, v = _req(q, "q"), _req(k, "k"), _req(v, "v")
         B, Q, E = q.shape
@@ -247,6 +266,7 @@ class _MaskedXAttn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         q, k, v, mask, row_open, out, lse = ctx.saved_tensors
         grad_out = _req(grad_out, "grad_out")
@@ -276,16 +296,16 @@ def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, 
     mask_logits (NL,B,Q,h,w) or a list of NL (B,Q,h,w) tensors (not stacked); class_logits (NL,B,Q,C1); tgt_masks (sum T, Ht, Wt) fp32 or uint8;
     tgt_counts: python list of T_i; tgt_classes (sum T,) int64; points (NL,B,P,2).
     Returns cost (NL,B,Q,Tmax) fp32 on the device; columns >= T_i are zero."""
-    class_logits, points = _req(class_logits, "class_logits"), _req(points, "points")
+    class_logits, points = _req(_f32(class_logits), "class_logits"), _req(_f32(points), "points")
     levels = None
     if isinstance(mask_logits, (list, tuple)):  # one (B,Q,h,w) tensor per level, used where it is
-        levels = [_req(m, "mask level") for m in mask_logits]
+        levels = [_req(_f32(m), "mask level") for m in mask_logits]
         mask_logits = levels[0]
         NL, (B, Q, h, w) = len(levels), mask_logits.shape
         if any(m.shape != mask_logits.shape for m in levels):
             raise ValueError("matcher_cost: level tensors of different shapes")
     else:
-        mask_logits = _req(mask_logits, "mask_logits")
+        mask_logits = _req(_f32(mask_logits), "mask_logits")
         NL, B, Q, h, w = mask_logits.shape
     C1 = class_logits.shape[-1]
     P = points.shape[2]
@@ -322,6 +342,7 @@ def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, 
 # ----------------------------------------------------------------------------------------- point sampling
 class _PointSample(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, feat, pts, map_index):
         tdt = 1 if feat.dtype in (torch.uint8, torch.bool) else 0
         if feat.dtype == torch.bool:
@@ -348,6 +369,7 @@ class _PointSample(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         pts, map_index = ctx.saved_tensors
         N, H, W = ctx.shape
@@ -462,6 +484,7 @@ def _ptr_table(tensors):
 
 class _PointSampleLevels(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, pts, index, neg_abs, *maps):
         maps = [_req(m, "level map") for m in maps]
         pts, index = _req(pts, "pts"), _req(index, "index", torch.int32)
@@ -479,6 +502,7 @@ class _PointSampleLevels(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         pts, index = ctx.saved_tensors
         NL, N, H, W = ctx.shape
@@ -499,6 +523,7 @@ def point_sample_levels(maps, pts: torch.Tensor, index: torch.Tensor, neg_abs: b
 
 class _MaskLossRows(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, logits, labels):
         logits, labels = _req(logits, "logits"), _req(labels, "labels")
         R, P = logits.shape
@@ -511,6 +536,7 @@ class _MaskLossRows(torch.autograd.Function):
         return bce, dice
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_bce, g_dice):
         logits, labels, sums = ctx.saved_tensors
         R, P = logits.shape
