@@ -155,12 +155,12 @@ def main():
         value = world * B * a.steps / dt
         line = {
             "metric": "images/sec at 1024x1024 bs=8 per GPU (Mask2Former R50, 100 queries, "
-                      + ("fp32 forward-only)" if a.mode == "fwd" else "full train step)"),
+                      + ("fp32" if a.amp == "off" else "bf16-autocast") + (" forward-only)" if a.mode == "fwd" else " full train step)"),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.amp == "off" else "bf16 autocast (stock ops bf16, wm2f kernels f32)", "data": "synthetic (randn pixels, random-init weights seed 0)",
             "config": {"workload": f"BASELINE.json configs[1]: synthetic {S}x{S} 3-class, ResNet-50 Mask2Former, "
-                                   f"100 queries, fp32 {'forward-only' if a.mode == 'fwd' else 'train step'}, "
+                                   f"100 queries, {'fp32' if a.amp == 'off' else 'bf16 autocast'} {'forward-only' if a.mode == 'fwd' else 'train step'}, "
                                    f"bs={B} per GPU", "global_batch": world * B, "image_size": S,
                        "parallelism": f"dp{world}", "mode": a.mode},
         }
