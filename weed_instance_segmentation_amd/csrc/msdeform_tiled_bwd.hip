@@ -13,12 +13,14 @@
 // Points whose footprint leaves the window fall back to global loads / global atomics, so results do
 // not depend on the margin.
 //
-// Measured (config 2, one call): kernel A 0.52 ms; kernel B 10.3 ms, ALL of it in the ds_add_f32 stream
+// [round-1 history] With fp32 LDS atomics: kernel A 0.52 ms; kernel B 10.3 ms, ALL of it in the ds_add_f32 stream
 // (ablation: without the flush 10.3 ms, without the LDS adds 0.2 ms): an LDS float atomic costs ~176
 // cycles per wave-instruction (~2.7 cycles per lane) whether or not lanes conflict -- the wave-per-query
 // form below (two contiguous 128-B rows per instruction) runs exactly as long as a scattered form did.
-// Total 10.8 ms vs 25 ms for the global-atomic backward.  The next step is an atomic-free accumulation
-// (channel groups owned by waves + in-order read-modify-write), estimated at 1.5 ms.
+// Total 10.8 ms vs 25 ms for the global-atomic backward.
+// Now: the window accumulates in FIXED POINT with integer LDS atomics (~5 cycles per wave-instruction, measured by
+// tools/probes/lds_atomic_rate.hip; scaling and its overflow bound are at the accumulation site):
+// kernel B 2.31 ms, kernel A 0.51 ms.
 #include "msdeform_tiled.h"
 
 namespace wm2f {
@@ -214,7 +216,29 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
   float* gvb = grad_value + ((int64_t)c.b * S * heads + c.h) * D;
 
   for (int i = tid; i < g.lv_tab_off4; i += kBwdThreads) win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Fixed-point accumulation.  An LDS float atomic costs ~190 cycles per wave-instruction on gfx950, an integer one
+  // ~5 (tools/probes/lds_atomic_rate.hip), so the window holds int32 sums of round(x * scale[channel]).
+  // scale = 2^31 / (512 * max|grad_out| of this tile, head and channel): a window element receives from each of the
+  // tile's <= 336 queries at most sum_p attention_weight <= 1 times a bilinear weight <= 1 of that query's
+  // grad_out, so |sum| <= 336 * max < 2^31 / scale -- the integer sum cannot overflow.  Each addend is rounded to
+  // 2^-22 * max (the fp32 sum it replaces rounds each partial sum to 2^-24 of its own magnitude).
+  __shared__ float ch_max[kBwdThreads / kWave][32];
+  {
+    float m = 0.f;
+    for (int qi = wave; qi < c.nq; qi += kWaves) {
+      const int q = tile_query<NL>(lv_tab, qi, Q);
+      m = fmaxf(m, fabsf(grad_out[(((int64_t)c.b * Q + q) * heads + c.h) * D + ch]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (lane < 32) ch_max[wave][lane] = m;
+  }
   __syncthreads();
+  float gmax = 0.f;
+#pragma unroll
+  for (int w = 0; w < kBwdThreads / kWave; ++w) gmax = fmaxf(gmax, ch_max[w][ch]);
+  const float fx_scale = gmax > 0.f ? 4194304.f / gmax : 0.f;  // 2^22 / max
+  const float fx_inv = gmax > 0.f ? gmax * (1.f / 4194304.f) : 0.f;
+  int* wini = reinterpret_cast<int*>(win);
 
   // this lane's point (lanes >= NP idle in the per-point phase): level constants
   const int pl = lane < NP ? lane / P : 0;
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
     const int q = tile_query<NL>(lv_tab, qi, Q);
     const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
     const float gof = grad_out[pair * D + ch];
+    const float gofs = gof * fx_scale;
     // ---- per-point phase (one lane per point)
     float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
     int lds_idx = -1, glb_idx = 0, flags = 0;  // flags: bit0..3 corner in image, bit4 footprint in window
@@ -270,8 +295,8 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
       const float wt = hs ? s01 : s00, wb = hs ? s11 : s10;
       const bool ok_t = (f >> hs) & 1, ok_b = (f >> (2 + hs)) & 1;
       if (f & 16) {  // whole footprint inside the window: LDS accumulation
-        if (ok_t) atomicAdd(winf + li + hs * 32 + ch, wt * gof);
-        if (ok_b) atomicAdd(winf + li + (wwp + hs) * 32 + ch, wb * gof);
+        if (ok_t) atomicAdd(wini + li + hs * 32 + ch, __float2int_rn(wt * gofs));
+        if (ok_b) atomicAdd(wini + li + (wwp + hs) * 32 + ch, __float2int_rn(wb * gofs));
       } else {  // rare: straight to memory
         if (ok_t) atomicAdd(gvb + (int64_t)(gi + hs) * row_stride + ch, wt * gof);
         if (ok_b) atomicAdd(gvb + (int64_t)(gi + Wlp + hs) * row_stride + ch, wb * gof);
@@ -286,14 +311,14 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
     const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l];
     const int npix = ww * g.win_h[l];
     const float inv_ww = 1.f / (float)ww;
-    const float* wlf = winf + g.lds_off4[l] * 4;
+    const int* wli = wini + g.lds_off4[l] * 4;
     float* glev = gvb + (int64_t)g.start[l] * row_stride;
     for (int idx = pslot; idx < npix; idx += kBwdThreads / 32) {
       const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
       const int x = c.wx0[l] + wx, y = c.wy0[l] + wy;
       if (x < 0 || x >= Wl || y < 0 || y >= Hl) continue;
-      const float v = wlf[idx * 32 + ch];
-      if (v != 0.f) atomicAdd(glev + (int64_t)(y * Wl + x) * row_stride + ch, v);
+      const int vi = wli[idx * 32 + ch];
+      if (vi != 0) atomicAdd(glev + (int64_t)(y * Wl + x) * row_stride + ch, (float)vi * fx_inv);
     }
   }
 }
