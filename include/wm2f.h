@@ -190,6 +190,9 @@ int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y
 int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,
                        const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
                        int64_t pos_rows, float eps, void* stream);
+/* wm2f_tokens_to_nchw: out (B, C, HW) = tokens (B, S, C) rows [start, start + HW) transposed per image -- the
+ *                      `hidden[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` of HF:1384-1391. */
+int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int start, int HW, void* stream);
 
 /* ---- point-sampled mask loss, batched over the prediction levels --------
  * Replaces, for all levels of a step in one launch each, the per-level tensor work of Mask2FormerLoss.loss_masks

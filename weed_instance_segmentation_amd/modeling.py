@@ -224,10 +224,17 @@ class Mask2FormerPixelDecoder(nn.Module):
         hidden = torch.cat([e.flatten(2).transpose(1, 2) for e in embeds], 1)
         pos = torch.cat(poss, 0).contiguous()  # (S, C): identical for every image of the batch
         hidden = self.encoder(hidden, pos, level_hw)
-        outs, start = [], 0
+        outs, tokens, start = [], [], 0
+        fast = (not torch.is_grad_enabled() and hidden.is_cuda and hidden.dtype == torch.float32
+                and not torch.is_autocast_enabled("cuda"))
         for h, w in level_hw:
-            outs.append(hidden[:, start:start + h * w].transpose(1, 2).reshape(B, d, h, w))
+            tokens.append(hidden[:, start:start + h * w])  # (B, hw, C) views: what the transformer decoder consumes
+            if fast:  # tiled transpose instead of a generic strided copy (0.9 ms -> <0.1 ms for the finest level)
+                outs.append(ops.tokens_to_nchw(hidden, start, h, w))
+            else:
+                outs.append(hidden[:, start:start + h * w].transpose(1, 2).reshape(B, d, h, w))
             start += h * w
+        self._last_tokens = tokens
         n = self.num_fpn_levels
         for idx, feat in enumerate(features[:n][::-1]):  # HF:1395-1405
             k = n - idx
@@ -247,6 +254,10 @@ class Mask2FormerPixelLevelModule(nn.Module):
         feats = self.encoder(pixel_values)
         mask_features, multi_scale = self.decoder(feats)
         return feats, mask_features, multi_scale
+
+    def last_tokens(self):
+        """Token-layout (B, hw, C) views of the three multi-scale maps of the last forward."""
+        return self.decoder._last_tokens
 
 
 # ------------------------------------------------------------------------------ transformer decoder
@@ -366,11 +377,14 @@ class MaskedAttentionDecoder(nn.Module):
         inter = [self.layernorm(h)]
         logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0])
         all_logits = [logits]
+        keys_in = [None, None, None]  # feats[lvl] + poss[lvl]: the same for the three layers that attend to a level
         for idx, layer in enumerate(self.layers):
             if self.training and self.layerdrop > 0 and float(torch.rand([])) < self.layerdrop:  # HF:1905-1908
                 continue
             lvl = idx % 3
-            k, v = layer.cross_attn.project_kv(feats[lvl] + poss[lvl], feats[lvl])
+            if keys_in[lvl] is None:
+                keys_in[lvl] = feats[lvl] + poss[lvl]
+            k, v = layer.cross_attn.project_kv(keys_in[lvl], feats[lvl])
             h = layer(h, qpos, k, v, mask, row_open)
             inter.append(self.layernorm(h))
             logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[(idx + 1) % 3])
@@ -395,7 +409,8 @@ class Mask2FormerTransformerModule(nn.Module):
         self.decoder = MaskedAttentionDecoder(config)
         self.level_embed = nn.Embedding(3, d)
 
-    def forward(self, multi_scale, mask_features):
+    def forward(self, multi_scale, mask_features, tokens=None):
+        """tokens: optional (B, hw, C) token-layout views of `multi_scale` (saves re-flattening the NCHW maps)."""
         d = self.config.hidden_dim
         B = mask_features.shape[0]
         feats, poss, sizes = [], [], []
@@ -404,7 +419,8 @@ class Mask2FormerTransformerModule(nn.Module):
             sizes.append((int(f.shape[2]), int(f.shape[3])))
             pe = sine_position_embedding(f.shape[2], f.shape[3], d // 2, f.device, f.dtype)
             poss.append(pe.flatten(1).transpose(0, 1)[None])  # (1, HW, C)
-            feats.append(f.flatten(2).transpose(1, 2) + self.level_embed.weight[i][None, None, :])  # (B, HW, C)
+            tok = tokens[i] if tokens is not None else f.flatten(2).transpose(1, 2)
+            feats.append(tok + self.level_embed.weight[i][None, None, :])  # (B, HW, C)
         qpos = self.queries_embedder.weight[None].expand(B, -1, -1)
         h = self.queries_features.weight[None].expand(B, -1, -1)
         return self.decoder(h, qpos, feats, poss, mask_features, sizes)
@@ -501,7 +517,8 @@ class Mask2FormerForUniversalSegmentation(nn.Module):
         if output_attentions:
             raise NotImplementedError("output_attentions: attention maps are never materialised by the kernels")
         feats, mask_features, multi_scale = self.model.pixel_level_module(pixel_values)
-        h, inter, all_logits = self.model.transformer_module(multi_scale, mask_features)
+        h, inter, all_logits = self.model.transformer_module(multi_scale, mask_features,
+                                                             tokens=self.model.pixel_level_module.last_tokens())
         all_classes = [self.class_predictor(s) for s in inter]
         aux = [{"masks_queries_logits": m, "class_queries_logits": c} for m, c in zip(all_logits[:-1], all_classes[:-1])]
         loss = loss_dict = indices = None

@@ -426,6 +426,16 @@ def add_layernorm(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None
     return (out, out_pos) if pos is not None else out
 
 
+def tokens_to_nchw(tokens: torch.Tensor, start: int, h: int, w: int) -> torch.Tensor:
+    """tokens (B, S, C) rows [start, start + h*w) -> (B, C, h, w), tiled transpose (inference only, no autograd)."""
+    tokens = _req(tokens, "tokens")
+    B, S, C = tokens.shape
+    out = torch.empty(B, C, h, w, device=tokens.device, dtype=torch.float32)
+    with torch.cuda.device(tokens.device):
+        check(load().wm2f_tokens_to_nchw(_p(tokens), _p(out), B, S, C, int(start), h * w, _stream(tokens)), "wm2f_tokens_to_nchw")
+    return out
+
+
 # ------------------------------------------------------------------ instance post-processing (SURVEY 8f rank 2)
 _GRID = (384, 384)  # the dependency's hard-coded intermediate size (image_processing_mask2former.py:680-682)
 
