@@ -374,6 +374,9 @@ class MaskedAttentionDecoder(nn.Module):
         self.mask_predictor = MaskPredictor(config.hidden_dim, config.num_attention_heads, config.mask_feature_size)
 
     def forward(self, h, qpos, feats, poss, mask_features, sizes):
+        if mask_features.dtype != torch.float32:
+            # bf16 autocast: K3 computes in fp32 (ops._amp_fwd would convert this 268 MB tensor on each of its 10 calls)
+            mask_features = mask_features.float()
         inter = [self.layernorm(h)]
         logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0])
         all_logits = [logits]
