@@ -120,7 +120,7 @@ def test_k1_tiled_local_offsets(ops, shapes, B, fused):
                                       ([(32, 32), (64, 64), (128, 128)], 6)])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("spread", ["local", "wide"])
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_k1_quad_kernel(ops, shapes, B, fused, spread, variant):
     """Phased quad kernel (variant 3) and its streaming form (variant 4: persistent workgroups + loader waves; what
     `auto` picks for the encoder's 1:2:4 pyramids): ragged edge tiles, several tiles per workgroup,

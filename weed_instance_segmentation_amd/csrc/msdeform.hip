@@ -278,7 +278,8 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
 // variant: 0 = auto (phased quad kernel, else LDS-window kernel, else direct gather), 1 = direct,
 //          2 = LDS-window kernel only; 12/22/32/42/52/62 = its timing ablations (invalid outputs
 //          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations;
-//          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads
+//          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads;
+//          5 = streaming kernel with per-window flags instead of workgroup barriers
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -289,10 +290,10 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   WM2F_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {8,16,32,64}", who, D);
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
-  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4)) {
+  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || variant == 5)) {
     bool handled = false;
     if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
-                                      variant / 10, 0, 0))
+                                      variant == 5 ? 100 : variant / 10, 0, 0))
       return rc;
     if (handled) return WM2F_OK;
     if (variant != 0) {

@@ -144,15 +144,19 @@ struct Prod {
   float w00, w01, w10, w11;
 };
 
+// `base`: 0, or the window's LDS byte address -- then the published address is absolute and a consumer needs one add
+// (its lane offset) per half instead of two (streaming kernel; the phased kernel keeps window-relative addresses
+// because its window reads must stay visibly based on the window's __shared__ array for the LDS-DMA tracking).
 template <int LV>
-__device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, int wy0, bool valid, unsigned& slow) {
+__device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, int wy0, bool valid, unsigned& slow,
+                                        int base = 0) {
   constexpr int WW = Win<LV>::side;
   const float x0f = floorf(px), y0f = floorf(py);
   const int xr = (int)x0f - wx0, yr = (int)y0f - wy0;
   const bool fast = ((unsigned)xr < (unsigned)(WW - 1)) & ((unsigned)yr < (unsigned)(WW - 1));
   const bool use = fast & valid;
   Prod p;
-  p.addr = use ? (yr * WW + xr) * 128 : 0;
+  p.addr = base + (use ? (yr * WW + xr) * 128 : 0);
   const float a = use ? aw : 0.f;
   slow |= (valid & !fast) ? (1u << LV) : 0u;
   const float fx1 = px - x0f, fy1 = py - y0f;
@@ -171,8 +175,10 @@ __device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, i
 struct Corners {
   float4 v[8];
 };
+typedef const __attribute__((address_space(3))) float4* lds_cf4_t;
 struct PointAddr {  // where the quad reads a point, and its four corner weights
-  const float4 *c1, *c2;
+  const float4 *c1, *c2;  // window-relative form (win != nullptr)
+  int a1, a2;             // absolute LDS byte addresses (win == nullptr: the producer folded the window base in)
   float q[4];
 };
 
@@ -184,72 +190,86 @@ __device__ __forceinline__ PointAddr point_addr(const float4* win, const Prod& p
   a.q[1] = bcast<K>(p.w01);
   a.q[2] = bcast<K>(p.w10);
   a.q[3] = bcast<K>(p.w11);
-  const char* base = reinterpret_cast<const char*>(win);
-  a.c1 = reinterpret_cast<const float4*>(base + ak + off1);
-  a.c2 = reinterpret_cast<const float4*>(base + ak + off2);
+  a.c1 = a.c2 = nullptr;
+  a.a1 = a.a2 = 0;
+  if (win) {
+    const char* base = reinterpret_cast<const char*>(win);
+    a.c1 = reinterpret_cast<const float4*>(base + ak + off1);
+    a.c2 = reinterpret_cast<const float4*>(base + ak + off2);
+  } else {
+    a.a1 = ak + off1;
+    a.a2 = ak + off2;
+  }
   return a;
 }
 
-template <int LV, int I, int MODE>
+template <int LV, int I, int MODE, bool ABS>
 __device__ __forceinline__ float4 read_corner(const PointAddr& a) {
   constexpr int WW = Win<LV>::side;
   constexpr int o = (I & 1) * 8 + ((I >> 1) & 1) * WW * 8;  // corner order: 00, 01, 10, 11
   if (MODE == 4) {  // ablation: no LDS reads
-    asm volatile("" ::"v"(a.c1), "v"(a.c2));
+    if (ABS) asm volatile("" ::"v"(a.a1), "v"(a.a2));
+    else asm volatile("" ::"v"(a.c1), "v"(a.c2));
     return make_float4(a.q[0], a.q[1], a.q[2], a.q[3]);
+  }
+  if (ABS) {  // an LDS address held as an integer; the cast chain keeps the access a ds_read (address-space inference)
+    const float4* gp = (const float4*)reinterpret_cast<lds_cf4_t>((size_t)((I < 4 ? a.a1 : a.a2) + o * 16));
+    return *gp;
   }
   return (I < 4 ? a.c1 : a.c2)[o];
 }
 
 // One level for all kPasses queries of the lane: 12 points (pass t, producer lane k), see Corners.
-template <int LV, int GI, int I, int MODE>
+template <int LV, int GI, int I, int MODE, bool ABS>
 __device__ __forceinline__ void corner_steps(Acc& acc, Corners& cr, const PointAddr& cur, const PointAddr& nxt) {
   if constexpr (I < 8) {
     if (I < 4) pk_fma4(acc.a_lo, acc.a_hi, cur.q[I & 3], cr.v[I]);
     else pk_fma4(acc.b_lo, acc.b_hi, cur.q[I & 3], cr.v[I]);
-    if constexpr (GI + 1 < kPasses * 4) cr.v[I] = read_corner<LV, I, MODE>(nxt);
+    if constexpr (GI + 1 < kPasses * 4) cr.v[I] = read_corner<LV, I, MODE, ABS>(nxt);
     __builtin_amdgcn_sched_barrier(0);
-    corner_steps<LV, GI, I + 1, MODE>(acc, cr, cur, nxt);
+    corner_steps<LV, GI, I + 1, MODE, ABS>(acc, cr, cur, nxt);
   }
 }
 
-template <int LV, int GI, int MODE>
+template <int LV, int GI, int MODE, bool ABS>
 __device__ __forceinline__ void pipe_step(const float4* win, Acc (&acc)[kPasses], const Prod (&pr)[kPasses], int off1,
                                           int off2, Corners& cr, const PointAddr& cur, bool skip_last) {
   if constexpr (GI < kPasses * 4) {
     if (GI == (kPasses - 1) * 4 && skip_last) return;  // wave-uniform: the last pass holds no query in this wave
     PointAddr nxt = cur;
-    if constexpr (GI + 1 < kPasses * 4) nxt = point_addr<LV, (GI + 1) & 3>(win, pr[(GI + 1) >> 2], off1, off2);
+    if constexpr (GI + 1 < kPasses * 4) nxt = point_addr<LV, (GI + 1) & 3>(ABS ? nullptr : win, pr[(GI + 1) >> 2], off1, off2);
     __builtin_amdgcn_sched_barrier(0);
-    corner_steps<LV, GI, 0, MODE>(acc[GI >> 2], cr, cur, nxt);
+    corner_steps<LV, GI, 0, MODE, ABS>(acc[GI >> 2], cr, cur, nxt);
     // Pin the sums here: the accumulators are only stored at the very end, and LLVM's code sinking otherwise
     // moves whole FMA chains down there (every corner then stays live across all three phases: 500+ spills).
     asm volatile("" : "+v"(acc[GI >> 2].a_lo), "+v"(acc[GI >> 2].a_hi), "+v"(acc[GI >> 2].b_lo), "+v"(acc[GI >> 2].b_hi));
-    pipe_step<LV, GI + 1, MODE>(win, acc, pr, off1, off2, cr, nxt, skip_last);
+    pipe_step<LV, GI + 1, MODE, ABS>(win, acc, pr, off1, off2, cr, nxt, skip_last);
   }
 }
 
-template <int LV, int I, int MODE>
+template <int LV, int I, int MODE, bool ABS>
 __device__ __forceinline__ void first_reads(Corners& cr, const PointAddr& a) {
   if constexpr (I < 8) {
-    cr.v[I] = read_corner<LV, I, MODE>(a);
-    first_reads<LV, I + 1, MODE>(cr, a);
+    cr.v[I] = read_corner<LV, I, MODE, ABS>(a);
+    first_reads<LV, I + 1, MODE, ABS>(cr, a);
   }
 }
 
-template <int LV, int MODE>
+template <int LV, int MODE, bool ABS = false>
 __device__ __forceinline__ void gather_phase(const float4* win, Acc (&acc)[kPasses], const float (&px)[kPasses][3],
                                              const float (&py)[kPasses][3], const float (&wt)[kPasses][3],
                                              const bool (&valid)[kPasses], int wx0, int wy0, unsigned (&slow)[kPasses],
                                              int off1, int off2, bool skip_last) {
   Prod pr[kPasses];
+  const int base = ABS ? (int)(size_t)(lds_cf4_t)win : 0;
 #pragma unroll
-  for (int t = 0; t < kPasses; ++t) pr[t] = produce<LV>(px[t][LV], py[t][LV], wt[t][LV], wx0, wy0, valid[t], slow[t]);
+  for (int t = 0; t < kPasses; ++t)
+    pr[t] = produce<LV>(px[t][LV], py[t][LV], wt[t][LV], wx0, wy0, valid[t], slow[t], base);
   Corners cr;
-  const PointAddr a0 = point_addr<LV, 0>(win, pr[0], off1, off2);
-  first_reads<LV, 0, MODE>(cr, a0);
+  const PointAddr a0 = point_addr<LV, 0>(ABS ? nullptr : win, pr[0], off1, off2);
+  first_reads<LV, 0, MODE, ABS>(cr, a0);
   __builtin_amdgcn_sched_barrier(0);
-  pipe_step<LV, 0, MODE>(win, acc, pr, off1, off2, cr, a0, skip_last);
+  pipe_step<LV, 0, MODE, ABS>(win, acc, pr, off1, off2, cr, a0, skip_last);
 }
 
 // Slow path for one point and 4 channels: per-corner image-bounds checks, corners from global memory.
@@ -654,7 +674,31 @@ struct Decode {
   bool valid[kPasses];
 };
 
-template <bool FUSED, int MODE>
+// ---- flags instead of workgroup barriers (SYNC = 1) ---------------------------------------------------------
+// With a barrier per phase all ten waves move in lock-step: everybody gathers (LDS saturated: the phases are bound
+// by LDS bandwidth, 8 ds_read_b128 per point), then everybody computes coordinates / fetches / stores (LDS idle).
+// Here each window has two `ready` counters (one per loader: "tiles loaded so far") and one `done` counter ("wave
+// passes finished reading it"); a gather wave only waits for the window it is about to read, a loader only for the
+// window it is about to overwrite.  Waves drift apart by up to a tile, so some gather while others do the rest.
+// The polls are bounded (a lost wake-up ends in wrong results that the tests catch, never in a hung GPU).
+constexpr int kCtrlReady = 0, kCtrlDone = 6, kCtrlWords = 12;
+__device__ __forceinline__ void poll_ge(int* p, int target) {
+  for (int it = 0; it < (1 << 22); ++it) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void publish(int* p, int v, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wave_done(int* p, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's window reads have returned
+  if (lane == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool FUSED, int MODE, int SYNC = 0>
 __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const float* __restrict__ value,
                                                                         const float* __restrict__ a_in,
                                                                         const float* __restrict__ b_in,
@@ -673,6 +717,11 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
   if (n_my <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row_stride = heads * D, row_bytes = row_stride * 4;
+  __shared__ int ctrl[kCtrlWords];
+  if (SYNC == 1) {
+    if (tid < kCtrlWords) ctrl[tid] = 0;
+    wg_barrier();
+  }
 
   if (wave >= kLoaderWave0) {
     // ------------------------------------------------------------------ loader waves
@@ -695,6 +744,27 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
     __builtin_amdgcn_sched_barrier(0);
     loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+    if (SYNC == 1) {
+      for (int k = 0; k < n_my; ++k) {
+        wait_vm<LWin<1>::n>();  // coarse(k) landed
+        publish(&ctrl[kCtrlReady + 0 * 2 + ld], k + 1, lane);
+        wait_vm<0>();           // mid(k) landed
+        publish(&ctrl[kCtrlReady + 1 * 2 + ld], k + 1, lane);
+        poll_ge(&ctrl[kCtrlDone + 2], kGatherWaves * k);  // every gather wave is done with fine(k - 1)
+        loader_issue<2, 0, LWin<2>::n>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+        wait_vm<0>();
+        publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
+        if (k + 1 < n_my) {
+          lt = loader_tile(value, sg, first + (k + 1) * stride, S, heads);
+          poll_ge(&ctrl[kCtrlDone + 0], kGatherWaves * (k + 1));
+          loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+          __builtin_amdgcn_sched_barrier(0);
+          poll_ge(&ctrl[kCtrlDone + 1], kGatherWaves * (k + 1));
+          loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+        }
+      }
+      return;
+    }
     for (int k = 0; k < n_my; ++k) {
       const bool more = k + 1 < n_my;
       wait_vm<LWin<1>::n>();  // coarse(k) landed; mid(k) may still fly
@@ -746,7 +816,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     float wt[kPasses][NL];
     int qrow[kPasses];
     bool valid[kPasses];
-    int wx0[NL], wy0[NL], b, h;
+    int wx0[NL], wy0[NL], b, h, tx, ty;
   };
   // reference point of token q (HF:1127-1156): ((column + 0.5) / W_l, (row + 0.5) / H_l) of its own level
   auto ref_point = [&](int q, float& rx, float& ry) __attribute__((always_inline)) {
@@ -765,6 +835,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     const TileId t = decode_tile(id, sg, heads);
     o.b = t.b;
     o.h = t.h;
+    o.tx = t.tx;
+    o.ty = t.ty;
     int nqx[NL], nqy[NL], key = 0;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -826,7 +898,12 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
 #pragma unroll
     for (int t = 0; t < kPasses; ++t) {
       float refx = 0.f, refy = 0.f;
-      if (FUSED) ref_point(cur.qrow[t] - cur.b * Q, refx, refy);
+      if (FUSED) {  // `dc` still describes this tile here: the next fetch (which may rebuild it) comes later
+        const int sh = dc.code[t] & 3;
+        const float sc = sh == 2 ? 0.25f : (sh == 1 ? 0.5f : 1.f);  // exact: rcp(W0 * 2^sh) == rcp(W0) * 2^-sh
+        refx = ((float)((cur.tx << (sh + 2)) + ((dc.code[t] >> 2) & 63)) + 0.5f) * (inv_w0 * sc);
+        refy = ((float)((cur.ty << (sh + 2)) + (dc.code[t] >> 8)) + 0.5f) * (inv_h0 * sc);
+      }
 #pragma unroll
       for (int l = 0; l < NL; ++l) wt[t][l] = cur.wt[t][l];
       if (FUSED) {  // softmax over the 12 logits of the quad (HF:986-991)
@@ -862,21 +939,32 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     }
     const bool skip_last = __builtin_amdgcn_ballot_w64(cur.valid[kPasses - 1]) == 0;
 
+    auto window_ready = [&](int w) __attribute__((always_inline)) {
+      if (SYNC == 1) {
+        poll_ge(&ctrl[kCtrlReady + w * 2 + 0], k + 1);
+        poll_ge(&ctrl[kCtrlReady + w * 2 + 1], k + 1);
+      } else {
+        wg_barrier();
+      }
+    };
     WM2F_SSTAMP(1, 0);
-    wg_barrier();  // Bc(k)
+    window_ready(0);  // Bc(k)
     WM2F_SSTAMP(2, 0);
-    gather_phase<0, MODE>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
+    gather_phase<0, MODE, true>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
+    if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 0], lane);
     WM2F_SSTAMP(3, 0);
-    wg_barrier();  // Bm(k)
+    window_ready(1);  // Bm(k)
     WM2F_SSTAMP(4, 0);
-    gather_phase<1, MODE>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
+    gather_phase<1, MODE, true>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
+    if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 1], lane);
     WM2F_SSTAMP(5, 0);
-    wg_barrier();  // Bf(k)
+    window_ready(2);  // Bf(k)
     WM2F_SSTAMP(6, 0);
     if (k + 1 < n_my) nxt = fetch(first + (k + 1) * stride);  // lands under the fine gather
     __builtin_amdgcn_sched_barrier(0);
     WM2F_SSTAMP(7, 0);
-    gather_phase<2, MODE>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
+    gather_phase<2, MODE, true>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
+    if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 2], lane);
     WM2F_SSTAMP(8, 0);
 
     // ---- slow points (rare), then the stores
@@ -1031,9 +1119,10 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_heads = 1.f / (float)heads;
   sg.inv_ntiles = 1.f / (float)(g.tiles_x * g.tiles_y);
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
-  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0>;
-  if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4>;
-  if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7>;
+  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0>;
+  if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0>;
+  if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0>;
+  if (mode == 100) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1>;  // flags instead of barriers
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(kSThreads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();
