@@ -22,6 +22,7 @@
 // Roofline: at fp32 the op is MFMA-bound, not HBM-bound: 4*B*heads*Q*N*D flop
 // (13.4 GFLOP at N = 16384, config 2) vs 2*B*N*heads*D*4 B of K/V (268 MB).
 #include "common.h"
+#include <stdlib.h>
 
 namespace wm2f {
 
@@ -29,9 +30,17 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kXWaves = 4;
 
-static inline int xattn_splits(int B, int heads, int N) {
+static inline int tune_env(const char* name, int dflt) {  // experiment knobs (tools/kbench.py); unset in production
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
+// Key splits.  Forward: measured at config 2 (tools/kbench.py --only k2, knobs WM2F_K2_QTILES / WM2F_K2_WG_TARGET):
+// 2 query tiles per workgroup (4 query chunks, ~150 registers -> 3 waves per SIMD instead of 1 at 7 tiles) and 512
+// (image, head, split) groups: 33 / 76 / 256 us at N = 1024 / 4096 / 16384 against 57 / 110 / 375 us before.
+static inline int xattn_splits(int B, int heads, int N, bool fwd = true) {
   const int n_tiles = ceil_div(N, 16);
-  int s = ceil_div(1024, B * heads);  // aim at >= 4 workgroups per CU-quarter of the chip
+  int s = ceil_div(fwd ? tune_env("WM2F_K2_WG_TARGET", 512) : 1024, B * heads);
   const int max_s = ceil_div(n_tiles, kXWaves);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -90,29 +99,47 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_kernel(
   if (t_end > n_tiles) t_end = n_tiles;
   const bool n_al4 = (N & 3) == 0;
 
-  for (int tile = split * tiles_per_split + wave; tile < t_end; tile += kXWaves) {
+  // K / V^T fragments of one 16-key tile.  K (A operand of S^T): lane (key = key0+n, d = DK*g + t);
+  // V^T (A operand of O^T): lane (d = 16i+n, key = key0+4g+t).  Loaded ONE TILE AHEAD of their use: with two waves
+  // per SIMD the global-load latency of a tile was exposed once per tile (no other work to hide it).
+  auto load_tile = [&](int tile, float (&kf_)[DK], float (&vf_)[DT][4]) __attribute__((always_inline)) {
     const int key0 = tile * 16;
-    // K fragment (A operand of S^T): lane (key = key0+n, d = DK*g + t)
-    float kf[DK];
-    {
-      int kk = key0 + n;
-      if (kk > N - 1) kk = N - 1;
-      const float* kp = k + ((int64_t)b * N + kk) * E + h * D + DK * g;
+    int kk = key0 + n;
+    if (kk > N - 1) kk = N - 1;
+    const float* kp = k + ((int64_t)b * N + kk) * E + h * D + DK * g;
 #pragma unroll
-      for (int t = 0; t < DK; t += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(kp + t);
-        kf[t] = x.x; kf[t + 1] = x.y; kf[t + 2] = x.z; kf[t + 3] = x.w;
-      }
+    for (int t = 0; t < DK; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(kp + t);
+      kf_[t] = x.x; kf_[t + 1] = x.y; kf_[t + 2] = x.z; kf_[t + 3] = x.w;
     }
-    // V^T fragments (A operand of O^T): lane (d = 16i+n, key = key0+4g+t)
-    float vf[DT][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       int vk = key0 + 4 * g + t;
       if (vk > N - 1) vk = N - 1;
       const float* vp = v + ((int64_t)b * N + vk) * E + h * D + n;
 #pragma unroll
-      for (int i = 0; i < DT; ++i) vf[i][t] = vp[16 * i];
+      for (int i = 0; i < DT; ++i) vf_[i][t] = vp[16 * i];
+    }
+  };
+  float kf_next[DK], vf_next[DT][4];
+  {
+    int t_first = split * tiles_per_split + wave;
+    if (t_first > n_tiles - 1) t_first = n_tiles - 1;  // n_tiles >= 1; keeps the loads in range when this wave has no tile
+    load_tile(t_first, kf_next, vf_next);
+  }
+  for (int tile = split * tiles_per_split + wave; tile < t_end; tile += kXWaves) {
+    const int key0 = tile * 16;
+    float kf[DK], vf[DT][4];
+#pragma unroll
+    for (int t = 0; t < DK; ++t) kf[t] = kf_next[t];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vf[i][t] = vf_next[i][t];
+    {
+      int t_n = tile + kXWaves;
+      if (t_n > n_tiles - 1) t_n = n_tiles - 1;  // the last prefetch re-reads a valid tile and is discarded
+      load_tile(t_n, kf_next, vf_next);
     }
 
     // ---- S^T = K Q^T
@@ -273,8 +300,8 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
   const int n_splits = xattn_splits(B, heads, N);
   const int n_tiles = ceil_div(N, 16);
   const int tps = ceil_div(n_tiles, n_splits);
-  // query row tiles per pass: 7 (D <= 32) or 3 (D = 64, register budget)
-  const int cap = (D == 64) ? 3 : 7;
+  // query row tiles per workgroup: 2 (see xattn_splits; D = 64: at most 3 by register budget)
+  const int cap = (D == 64) ? 2 : tune_env("WM2F_K2_QTILES", 2);
   const int q_tiles = ceil_div(Q, 16);
   const int q_chunks = ceil_div(q_tiles, cap);
   int nqt = ceil_div(q_tiles, q_chunks);
@@ -535,7 +562,7 @@ __global__ __launch_bounds__(256) void xattn_dq_reduce_kernel(const float* __res
 extern "C" int64_t wm2f_masked_xattn_bwd_workspace(int B, int heads, int Q, int N, int D) {
   if (B <= 0 || heads <= 0 || Q <= 0 || N <= 0 || D <= 0) return 0;
   // dQ partials per split + delta
-  return ((int64_t)B * heads * Q * xattn_splits(B, heads, N) * D + (int64_t)B * heads * Q) * 4;
+  return ((int64_t)B * heads * Q * xattn_splits(B, heads, N, false) * D + (int64_t)B * heads * Q) * 4;
 }
 
 extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v, const void* mask,
@@ -548,7 +575,7 @@ extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v
   WM2F_REQUIRE(B > 0 && heads > 0 && Q > 0 && N > 0, "%s: non-positive size", who);
   WM2F_REQUIRE(D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {16,32,64}", who, D);
   WM2F_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads / B exceed the grid limits", who);
-  const int n_splits = xattn_splits(B, heads, N);
+  const int n_splits = xattn_splits(B, heads, N, false);
   const int tps = ceil_div(ceil_div(N, 16), n_splits);
   hipStream_t st = (hipStream_t)stream;
   float* dq_ws = (float*)workspace;
