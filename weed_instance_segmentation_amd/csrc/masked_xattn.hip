@@ -247,6 +247,177 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_kernel(
   }
 }
 
+// Query-split form of the kernel above (selectable with WM2F_K2_QSPLIT=1, not the default): the 4 waves of a workgroup walk the SAME
+// key tiles of a split and each owns NQT query tiles of its own, so K / V are fetched from L2 once per (image, head,
+// split) -- the waves' identical fragment loads meet in the CU's L1 -- while a wave still carries only NQT = 2 tiles
+// of state (3 waves per SIMD).  No cross-wave merge: every wave writes its queries' partial (O, m, l) directly.
+template <int NQT, int D>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_qsplit_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, float* __restrict__ ws, int Q, int N,
+    int heads, int n_splits, int tiles_per_split) {
+  constexpr int DK = D / 4;   // k-steps of S^T: lane group g owns d = DK*g .. DK*g+DK-1
+  constexpr int DT = D / 16;  // 16-row tiles of O^T
+  constexpr int QL = NQT * 16;  // queries of ONE WAVE; a workgroup covers kXWaves * QL
+  constexpr int RS = D + 4;     // workspace row: O[D], m, l, pad, pad (keeps float4 alignment)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x % n_splits, qc = blockIdx.x / n_splits;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = (qc * kXWaves + wave) * QL;
+  if (q0 >= Q) return;  // no barrier in this kernel: a wave without queries just leaves
+  const int E = heads * D;
+  const float NEG_INF = -INFINITY;
+
+  // ---- Q^T fragments (B operand), kept for the whole kernel
+  float qf[NQT][DK];
+  int qrow[NQT];
+  bool use_mask[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    int qi = q0 + 16 * j + n;
+    if (qi > Q - 1) qi = Q - 1;  // padding rows replay the last query; never stored
+    qrow[j] = qi;
+    const float* qp = q + ((int64_t)b * Q + qi) * E + h * D + DK * g;
+#pragma unroll
+    for (int t = 0; t < DK; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(qp + t);
+      qf[j][t] = x.x; qf[j][t + 1] = x.y; qf[j][t + 2] = x.z; qf[j][t + 3] = x.w;
+    }
+    use_mask[j] = mask != nullptr && (row_open == nullptr || row_open[(int64_t)b * Q + qi] != 0);
+  }
+
+  f32x4 o[DT][NQT];
+  float m[NQT], l[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    m[j] = NEG_INF;
+    l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int n_tiles = ceil_div(N, 16);
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+  const bool n_al4 = (N & 3) == 0;
+
+  // K / V^T fragments of one 16-key tile.  K (A operand of S^T): lane (key = key0+n, d = DK*g + t);
+  // V^T (A operand of O^T): lane (d = 16i+n, key = key0+4g+t).  Loaded ONE TILE AHEAD of their use: with two waves
+  // per SIMD the global-load latency of a tile was exposed once per tile (no other work to hide it).
+  auto load_tile = [&](int tile, float (&kf_)[DK], float (&vf_)[DT][4]) __attribute__((always_inline)) {
+    const int key0 = tile * 16;
+    int kk = key0 + n;
+    if (kk > N - 1) kk = N - 1;
+    const float* kp = k + ((int64_t)b * N + kk) * E + h * D + DK * g;
+#pragma unroll
+    for (int t = 0; t < DK; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(kp + t);
+      kf_[t] = x.x; kf_[t + 1] = x.y; kf_[t + 2] = x.z; kf_[t + 3] = x.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int vk = key0 + 4 * g + t;
+      if (vk > N - 1) vk = N - 1;
+      const float* vp = v + ((int64_t)b * N + vk) * E + h * D + n;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) vf_[i][t] = vp[16 * i];
+    }
+  };
+  float kf_next[DK], vf_next[DT][4];
+  {
+    int t_first = split * tiles_per_split;
+    if (t_first > n_tiles - 1) t_first = n_tiles - 1;  // n_tiles >= 1; keeps the loads in range when this wave has no tile
+    load_tile(t_first, kf_next, vf_next);
+  }
+  for (int tile = split * tiles_per_split; tile < t_end; ++tile) {
+    const int key0 = tile * 16;
+    float kf[DK], vf[DT][4];
+#pragma unroll
+    for (int t = 0; t < DK; ++t) kf[t] = kf_next[t];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vf[i][t] = vf_next[i][t];
+    {
+      int t_n = tile + 1;
+      if (t_n > n_tiles - 1) t_n = n_tiles - 1;  // the last prefetch re-reads a valid tile and is discarded
+      load_tile(t_n, kf_next, vf_next);
+    }
+
+    // ---- S^T = K Q^T
+    f32x4 s[NQT];
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < DK; ++t) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[j][t], s[j], 0, 0, 0);
+    }
+
+    // ---- mask, online softmax (per query = per C column), rescale O
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      uint32_t mb = 0;
+      if (use_mask[j]) {
+        const uint8_t* mp = mask + ((int64_t)b * Q + qrow[j]) * N + key0 + 4 * g;
+        if (n_al4 && key0 + 4 * g + 3 < N) {
+          mb = *reinterpret_cast<const uint32_t*>(mp);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + 4 * g + r < N) mb |= (uint32_t)(mp[r] != 0) << (8 * r);
+        }
+      }
+      float tmax = NEG_INF;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dead = ((mb >> (8 * r)) & 0xffu) != 0 || (key0 + 4 * g + r >= N);
+        s[j][r] = dead ? NEG_INF : s[j][r];
+        tmax = fmaxf(tmax, s[j][r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, kWave));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, kWave));
+      const float m_new = fmaxf(m[j], tmax);
+      const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __expf(m[j] - m_safe);
+      m[j] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[j][r] - m_safe);
+        s[j][r] = p;
+        psum += p;
+      }
+      l[j] = l[j] * alpha + psum;  // lane-local partial sum; lane groups are merged at the end
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i][j] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i][t], s[j][t], o[i][j], 0, 0, 0);
+  }
+
+  // ---- each wave owns its queries: straight to the workspace (one partial per key split)
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    float lt = l[j];
+    lt += __shfl_xor(lt, 16, kWave);
+    lt += __shfl_xor(lt, 32, kWave);
+    const int qi = q0 + 16 * j + n;
+    if (qi >= Q) continue;
+    float* wrow = ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * RS;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(wrow + 16 * i + 4 * g) = o[i][j];
+    if (g == 0) *reinterpret_cast<float4*>(wrow + D) = make_float4(m[j], lt, 0.f, 0.f);
+  }
+}
+
 // Merge the per-split partials: one thread per (b, h, q, float4 chunk of D).
 template <int D>
 __global__ __launch_bounds__(256) void masked_xattn_merge_kernel(const float* __restrict__ ws,
@@ -319,7 +490,25 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
   else if (nqt <= 2) WM2F_XL(2, Dv)                  \
   else if (nqt <= 4) WM2F_XL(4, Dv)                  \
   else WM2F_XL(7, Dv)
-  if (D == 16) {
+  // query-split kernel: a workgroup covers kXWaves * NQT * 16 queries
+#define WM2F_XQ(NQTv, Dv)                                                                                      \
+  {                                                                                                            \
+    dim3 grid(n_splits* ceil_div(Q, kXWaves * NQTv * 16), heads, B);                                           \
+    hipLaunchKernelGGL((masked_xattn_fwd_qsplit_kernel<NQTv, Dv>), grid, block, 0, st, (const float*)q,        \
+                       (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,           \
+                       (float*)workspace, Q, N, heads, n_splits, tps);                                         \
+  }
+  // measured at config 2: 30 / 77 / 263 us, i.e. no better than the key-split form with 2 query tiles (33 / 75 / 258):
+  // the L2 re-read was not the limit, the serial MFMA -> softmax -> MFMA chain inside a wave is.  Kept selectable.
+  const bool qsplit = D <= 32 && tune_env("WM2F_K2_QSPLIT", 0) != 0;
+  if (qsplit) {
+    const int per_wave = ceil_div(q_tiles, kXWaves);  // query tiles a wave needs to cover Q with one workgroup
+    if (D == 16) {
+      if (per_wave <= 1) WM2F_XQ(1, 16) else WM2F_XQ(2, 16)
+    } else {
+      if (per_wave <= 1) WM2F_XQ(1, 32) else WM2F_XQ(2, 32)
+    }
+  } else if (D == 16) {
     WM2F_XD(16)
   } else if (D == 32) {
     WM2F_XD(32)
@@ -328,6 +517,7 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
     else if (nqt <= 2) WM2F_XL(2, 64)
     else WM2F_XL(3, 64)
   }
+#undef WM2F_XQ
 #undef WM2F_XD
 #undef WM2F_XL
   WM2F_CHECK_LAUNCH(who);
