@@ -213,3 +213,47 @@ def test_bf16_autocast_forward_and_train_step(tiny):
     finally:
         model.eval()
         model.zero_grad(set_to_none=True)
+
+
+@pytest.mark.parametrize("size", [(200, 333), (96, 160)])
+def test_forward_odd_sizes_match_oracle(tiny, size):
+    """Input sizes that are not multiples of 32 (BASELINE config 5 is 1333 x 800): the three levels are then not in
+    the exact 1 : 2 : 4 ratio, so K1 falls back from the streaming kernel to the generic LDS-window / direct kernels;
+    ragged tiles everywhere.  (96, 160) is the aligned control."""
+    g, cfg, model, sd = tiny
+    x = torch.randn(2, 3, *size, generator=torch.Generator().manual_seed(9))
+    res = O.forward(sd, json.loads(str(g["config_json"])), x)
+    with torch.no_grad():
+        out = model(pixel_values=x.cuda())
+    ref = res["masks_queries_logits"]
+    assert out.masks_queries_logits.shape == ref.shape
+    assert (out.masks_queries_logits.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+    torch.testing.assert_close(out.class_queries_logits.cpu(), res["class_queries_logits"], rtol=1e-3, atol=1e-3)
+
+
+def test_swin_backbone_model_matches_oracle():
+    """BASELINE configs 4 / 5 use Swin backbones: a small Swin + the wm2f pixel decoder / transformer decoder on the GPU
+    against the oracle fed with the same backbone features (the Swin backbone itself is pinned on CPU against the
+    dependency's SwinBackbone fixture in test_host_cpu.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    g = load_golden("full_tiny.npz")
+    cd = json.loads(str(g["config_json"]))
+    cd["backbone_config"] = {"model_type": "swin", "embed_dim": 16, "depths": [1, 1, 2, 1], "num_heads": [1, 2, 4, 4],
+                             "window_size": 4, "mlp_ratio": 2.0, "patch_size": 4, "num_channels": 3,
+                             "out_features": ["stage1", "stage2", "stage3", "stage4"], "drop_path_rate": 0.0}
+    cfg = Mask2FormerConfig.from_dict(cd)
+    torch.manual_seed(3)
+    model = Mask2FormerForUniversalSegmentation(cfg).eval()
+    x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        feats = model.model.pixel_level_module.encoder(x)  # CPU, stock ops
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    res = O.forward(sd, cfg.to_dict(), x, backbone_feats=[f.clone() for f in feats])
+    model = model.cuda()
+    with torch.no_grad():
+        out = model(pixel_values=x.cuda())
+    ref = res["masks_queries_logits"]
+    assert (out.masks_queries_logits.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+    torch.testing.assert_close(out.class_queries_logits.cpu(), res["class_queries_logits"], rtol=1e-3, atol=1e-3)
