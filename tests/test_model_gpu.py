@@ -257,3 +257,19 @@ def test_swin_backbone_model_matches_oracle():
     ref = res["masks_queries_logits"]
     assert (out.masks_queries_logits.cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-3
     torch.testing.assert_close(out.class_queries_logits.cpu(), res["class_queries_logits"], rtol=1e-3, atol=1e-3)
+
+
+def test_graphed_forward_equals_eager(tiny):
+    """HIP-graph capture of the label-free forward: same numbers as the eager call, also after the input changes."""
+    from weed_instance_segmentation_amd.graph import GraphedForward
+    g, cfg, model, _ = tiny
+    x1 = T(g["pixel_values"]).cuda()
+    x2 = torch.randn_like(x1)
+    fwd = GraphedForward(model, x1)
+    for x in (x1, x2, x1):
+        out = fwd(x)
+        with torch.no_grad():
+            ref = model(pixel_values=x)
+        scale = ref.masks_queries_logits.abs().max().item()
+        assert (out.masks_queries_logits - ref.masks_queries_logits).abs().max().item() / scale < 1e-5
+        torch.testing.assert_close(out.class_queries_logits, ref.class_queries_logits, rtol=1e-4, atol=1e-4)
