@@ -683,7 +683,7 @@ struct Decode {
 // The polls are bounded (a lost wake-up ends in wrong results that the tests catch, never in a hung GPU).
 constexpr int kCtrlReady = 0, kCtrlDone = 6, kCtrlWords = 12;
 __device__ __forceinline__ void poll_ge(int* p, int target) {
-  for (int it = 0; it < (1 << 22); ++it) {
+  for (int it = 0; it < (1 << 18); ++it) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
     __builtin_amdgcn_s_sleep(1);
   }
