@@ -99,6 +99,16 @@ int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const v
  * (int64 [8192][16], n_bytes <= 1 MiB).  Synchronous; no reference counterpart. */
 int wm2f_debug_stamps(void* host_dst, int64_t n_bytes);
 
+/* ---- K3 in bf16 (BASELINE configs 3-5: bf16 autocast) ---------------------------------------------
+ * Same line as wm2f_mask_einsum_fwd (HF:2046) with bf16 operands, fp32 accumulation on the bf16 matrix cores and
+ * fp32 output; HBM-bound (478 MB per call at config 2).
+ *   emb (B, Q, C) bf16, Q <= 112 per call;  pix_pixel_major (B, HW, C) bf16 -- the pixel features PIXEL-MAJOR (the
+ *   MFMA operands want the contraction index contiguous), made once per forward by wm2f_nchw_to_pixel_major_bf16
+ *   from the (B, C, HW) map;  out (B, Q, HW) fp32;  C % 32 == 0, C <= 512. */
+int wm2f_mask_einsum_bf16_fwd(const void* emb, const void* pix_pixel_major, void* out, int B, int Q, int C,
+                              int HW, void* stream);
+int wm2f_nchw_to_pixel_major_bf16(const void* src, void* dst, int B, int C, int HW, void* stream);
+
 /* ---- K3: mask einsum --------------------------------------------------------------------
  * Replaces torch.einsum("bqc,bchw->bqhw"), HF:2046.
  *   emb (B, Q, C)   pix (B, C, HW)   out (B, Q, HW)      C % 16 == 0

@@ -239,6 +239,37 @@ def test_k3_random(ops, B, Q, C, H, W):
     assert torch.equal(ops.mask_einsum(dev(emb_i), dev(pix_i)).cpu(), torch.einsum("bqc,bchw->bqhw", emb_i, pix_i))
 
 
+@pytest.mark.parametrize("B,Q,C,H,W", [(2, 100, 256, 64, 64), (1, 7, 64, 5, 13), (2, 200, 256, 16, 24), (1, 112, 32, 33, 8)])
+def test_k3_bf16(ops, B, Q, C, H, W):
+    """bf16 operands on the bf16 matrix cores, fp32 accumulation and output: against the exact fp32 products of the
+    same bf16-rounded inputs (a bf16 x bf16 product is exact in fp32; only the summation order differs).  Ragged pixel
+    counts, fewer / more than 112 queries, and the pixel-major transpose."""
+    g = torch.Generator().manual_seed(31)
+    emb = torch.randn(B, Q, C, generator=g).to(torch.bfloat16)
+    pix = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16)
+    pix_t = ops.nchw_to_pixel_major_bf16(dev(pix))
+    assert torch.equal(pix_t.cpu(), pix.reshape(B, C, H * W).transpose(1, 2).contiguous())
+    out = ops.mask_einsum_bf16(dev(emb), dev(pix), pix_t)
+    ref = torch.einsum("bqc,bchw->bqhw", emb.float(), pix.float())
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_k3_bf16_backward(ops):
+    g = torch.Generator().manual_seed(32)
+    B, Q, C, H, W = 2, 20, 64, 8, 12
+    emb = torch.randn(B, Q, C, generator=g).to(torch.bfloat16)
+    pix = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16)
+    go = torch.randn(B, Q, H, W, generator=g)
+    e, p = dev(emb).requires_grad_(True), dev(pix).requires_grad_(True)
+    out = ops.mask_einsum_bf16(e, p, ops.nchw_to_pixel_major_bf16(p))
+    out.backward(dev(go))
+    er, pr = emb.float().requires_grad_(True), pix.float().requires_grad_(True)
+    torch.einsum("bqc,bchw->bqhw", er, pr).backward(go)
+    torch.testing.assert_close(e.grad.float().cpu(), er.grad, rtol=2e-2, atol=2e-1)  # bf16 GEMMs with bf16 outputs
+    torch.testing.assert_close(p.grad.float().cpu(), pr.grad, rtol=2e-2, atol=2e-1)
+
+
 def test_k3_backward(ops):
     g = torch.Generator().manual_seed(6)
     emb, pix = torch.randn(2, 20, 64, generator=g), torch.randn(2, 64, 8, 12, generator=g)

@@ -126,6 +126,17 @@ def main():
             logits = ops.mask_einsum(emb, pix)
             for hw in shapes:
                 res[f"attn_mask_build_{hw[0]}"] = timeit(lambda: ops.attn_mask_build(logits, hw), a.iters)
+    if "k3b" in only:  # K3 on the bf16 matrix cores (bf16 autocast path): HBM-bound
+        emb = torch.randn(B, Q, 256, device=dev).to(torch.bfloat16)
+        pix = torch.randn(B, 256, 256, 256, device=dev).to(torch.bfloat16)
+        r = timeit(lambda: ops.nchw_to_pixel_major_bf16(pix), a.iters)
+        r.update(bytes=2 * pix.numel() * 2, GBps=2 * pix.numel() * 2 / r["med_us"] / 1e3)
+        res["k3_bf16_pixel_major_transpose"] = r
+        pix_t = ops.nchw_to_pixel_major_bf16(pix)
+        r = timeit(lambda: ops.mask_einsum_bf16(emb, pix, pix_t), a.iters)
+        nb = pix.numel() * 2 + emb.numel() * 2 + B * Q * 65536 * 4
+        r.update(bytes=nb, GBps=nb / r["med_us"] / 1e3, flop=2 * B * Q * 256 * 65536)
+        res["k3_bf16_mask_einsum"] = r
     if "k2" in only:
         E = H * D
         q = torch.randn(B, Q, E, device=dev) * 0.3

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libwm2f.so")
-SOURCES = ["api.hip", "msdeform.hip", "msdeform_tiled.hip", "msdeform_quad.hip", "msdeform_tiled_bwd.hip", "mask_einsum.hip", "attn_mask.hip", "masked_xattn.hip", "matcher.hip", "fused_elementwise.hip", "postprocess.hip", "mask_loss.hip"]
+SOURCES = ["api.hip", "msdeform.hip", "msdeform_tiled.hip", "msdeform_quad.hip", "msdeform_tiled_bwd.hip", "mask_einsum.hip", "mask_einsum_bf16.hip", "attn_mask.hip", "masked_xattn.hip", "matcher.hip", "fused_elementwise.hip", "postprocess.hip", "mask_loss.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "msdeform_tiled.h"), os.path.join(os.path.dirname(HERE), "include", "wm2f.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]

@@ -356,8 +356,12 @@ class MaskPredictor(nn.Module):
         super().__init__()
         self.mask_embedder = _mlp_head(hidden, hidden, mask_feature_size)
 
-    def forward(self, h_norm, mask_features, next_size):
-        logits = ops.mask_einsum(self.mask_embedder(h_norm), mask_features)
+    def forward(self, h_norm, mask_features, next_size, pix_t=None):
+        """pix_t: the pixel-major bf16 copy of mask_features (bf16 autocast) -> K3 on the bf16 matrix cores."""
+        if pix_t is not None:
+            logits = ops.mask_einsum_bf16(self.mask_embedder(h_norm), mask_features, pix_t)
+        else:
+            logits = ops.mask_einsum(self.mask_embedder(h_norm), mask_features)
         mask, row_open = ops.attn_mask_build(logits, next_size)
         return logits, mask, row_open
 
@@ -374,11 +378,15 @@ class MaskedAttentionDecoder(nn.Module):
         self.mask_predictor = MaskPredictor(config.hidden_dim, config.num_attention_heads, config.mask_feature_size)
 
     def forward(self, h, qpos, feats, poss, mask_features, sizes):
-        if mask_features.dtype != torch.float32:
-            # bf16 autocast: K3 computes in fp32 (ops._amp_fwd would convert this 268 MB tensor on each of its 10 calls)
-            mask_features = mask_features.float()
+        pix_t = None
+        if (mask_features.dtype == torch.bfloat16 and mask_features.is_cuda and mask_features.shape[1] % 32 == 0
+                and mask_features.shape[1] <= 512):
+            # bf16 autocast: K3 runs on the bf16 matrix cores from a pixel-major copy made once for its 10 calls
+            pix_t = ops.nchw_to_pixel_major_bf16(mask_features.contiguous())
+        elif mask_features.dtype != torch.float32:
+            mask_features = mask_features.float()  # once, not once per mask-predictor call
         inter = [self.layernorm(h)]
-        logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0])
+        logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0], pix_t)
         all_logits = [logits]
         keys_in = [None, None, None]  # feats[lvl] + poss[lvl]: the same for the three layers that attend to a level
         for idx, layer in enumerate(self.layers):
@@ -390,7 +398,7 @@ class MaskedAttentionDecoder(nn.Module):
             k, v = layer.cross_attn.project_kv(keys_in[lvl], feats[lvl])
             h = layer(h, qpos, k, v, mask, row_open)
             inter.append(self.layernorm(h))
-            logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[(idx + 1) % 3])
+            logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[(idx + 1) % 3], pix_t)
             all_logits.append(logits)
         return h, inter, all_logits
 

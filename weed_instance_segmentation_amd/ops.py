@@ -223,6 +223,61 @@ def mask_einsum(emb: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
     return _MaskEinsum.apply(emb, pix)
 
 
+def nchw_to_pixel_major_bf16(pix: torch.Tensor) -> torch.Tensor:
+    """(B, C, H, W) bf16 -> (B, H*W, C) bf16 (tiled transpose; no autograd: used as saved data of mask_einsum_bf16)."""
+    pix = _req(pix.detach(), "pix", torch.bfloat16)
+    B, C, Hh, Ww = pix.shape
+    out = torch.empty(B, Hh * Ww, C, device=pix.device, dtype=torch.bfloat16)
+    with torch.cuda.device(pix.device):
+        check(load().wm2f_nchw_to_pixel_major_bf16(_p(pix), _p(out), B, C, Hh * Ww, _stream(pix)), "wm2f_nchw_to_pixel_major_bf16")
+    return out
+
+
+class _MaskEinsumBf16(torch.autograd.Function):
+    """bf16 operands, fp32 logits.  `pix_t` is the pixel-major copy of `pix` (made once per forward)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, emb, pix, pix_t):
+        emb = _req(emb if emb.dtype == torch.bfloat16 else emb.to(torch.bfloat16), "emb", torch.bfloat16)
+        pix_t = _req(pix_t, "pix_t", torch.bfloat16)
+        B, Q, C = emb.shape
+        Hh, Ww = pix.shape[2:]
+        if pix_t.shape != (B, Hh * Ww, C):
+            raise ValueError(f"mask_einsum_bf16: pix_t {tuple(pix_t.shape)} vs emb {tuple(emb.shape)}, pix {tuple(pix.shape)}")
+        out = torch.empty(B, Q, Hh, Ww, device=emb.device, dtype=torch.float32)
+        with torch.cuda.device(emb.device):
+            for q0 in range(0, Q, 112):  # the kernel holds at most 7 query tiles
+                q1 = min(Q, q0 + 112)
+                e = emb[:, q0:q1].contiguous() if (q0, q1) != (0, Q) else emb
+                o = out[:, q0:q1] if (q0, q1) != (0, Q) else out
+                oc = o if o.is_contiguous() else torch.empty(B, q1 - q0, Hh, Ww, device=emb.device, dtype=torch.float32)
+                check(_timed("mask_einsum_bf16_fwd", emb, lambda: load().wm2f_mask_einsum_bf16_fwd(
+                    _p(e), _p(pix_t), _p(oc), B, q1 - q0, C, Hh * Ww, _stream(emb))), "wm2f_mask_einsum_bf16_fwd")
+                if oc is not o:
+                    o.copy_(oc)
+        ctx.save_for_backward(emb, pix_t)
+        ctx.pix_shape = tuple(pix.shape)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, grad_out):
+        # Two plain batched GEMMs in bf16 (library GEMM through torch.bmm), as for the fp32 kernel.
+        emb, pix_t = ctx.saved_tensors
+        B, Q, C = emb.shape
+        go = grad_out.reshape(B, Q, -1).to(torch.bfloat16)
+        g_emb = torch.bmm(go, pix_t) if ctx.needs_input_grad[0] else None
+        g_pix = torch.bmm(emb.transpose(1, 2), go).view(ctx.pix_shape) if ctx.needs_input_grad[1] else None
+        return g_emb, g_pix, None
+
+
+def mask_einsum_bf16(emb: torch.Tensor, pix: torch.Tensor, pix_t: torch.Tensor) -> torch.Tensor:
+    """K3 under bf16 autocast: emb (B,Q,C), pix (B,C,H,W) bf16 (for shape and gradient), pix_t = nchw_to_pixel_major_bf16(pix)
+    -> fp32 logits (B,Q,H,W)."""
+    return _MaskEinsumBf16.apply(emb, pix, pix_t)
+
+
 def attn_mask_build(logits: torch.Tensor, size: Sequence[int]):
     """HF:2048-2054 + HF:1912-1914: (mask (B,Q,Hn*Wn) uint8 1=blocked, row_open (B,Q) int32).  No grad."""
     logits = _req(_f32(logits.detach()), "logits")
