@@ -224,7 +224,10 @@ def test_k3_golden(ops):
 
 @pytest.mark.parametrize("B,Q,C,H,W", [(2, 100, 256, 64, 64), (1, 200, 256, 32, 48), (2, 10, 64, 16, 24),
                                        (1, 37, 128, 20, 36), (1, 100, 256, 3, 12), (2, 20, 64, 8, 8), (1, 68, 256, 16, 16),
-                                       (1, 99, 256, 8, 16), (1, 224, 256, 8, 8)])
+                                       (1, 99, 256, 8, 16), (1, 224, 256, 8, 8),
+                                       # 1..4 rows over a multiple of 16 with small C (regression: wrong main-tile rows)
+                                       (2, 100, 64, 32, 48), (1, 200, 64, 24, 32), (2, 84, 64, 24, 32), (2, 100, 128, 32, 48),
+                                       (1, 200, 128, 24, 32), (2, 68, 32, 16, 20)])
 def test_k3_random(ops, B, Q, C, H, W):
     g = torch.Generator().manual_seed(5)
     emb = torch.randn(B, Q, C, generator=g)

@@ -200,7 +200,10 @@ extern "C" int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out,
   int rows_per_chunk = ceil_div(Q, q_chunks);
   int MT = rows_per_chunk / 16, REM = 0;
   const int left = rows_per_chunk - MT * 16;
-  if (left > 0 && left <= 4 && MT >= 1 && MT <= 6 && Q == q_chunks * rows_per_chunk) REM = 4;  // exact split only
+  // The VALU remainder path is used for C >= 128 only: with C = 64 (4 super-steps: the whole k-loop is straight-line
+  // code) it produced wrong rows in the MAIN tiles for some shapes (tools/probes/k3_grid_probe.py; cause not yet
+  // identified), so small C pads a row tile instead.
+  if (left > 0 && left <= 4 && MT >= 1 && MT <= 6 && Q == q_chunks * rows_per_chunk && C >= 128) REM = 4;  // exact split only
   else if (left > 0) MT += 1;
   if (MT > mt_cap) {  // fall back to plain padding with one more chunk
     q_chunks += 1;
