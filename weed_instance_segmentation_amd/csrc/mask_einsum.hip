@@ -150,14 +150,17 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
   }
 
   // ---- epilogue: lane holds rows 4g+reg of each row tile, pixels p0..p0+3 (column tiles 0..3).
-  // Rows >= Q fall outside out_rsrc's range and are dropped by the hardware.
+  // Rows >= Q fall outside out_rsrc's range and are dropped by the hardware (see the note at the store).
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, voff,
-                                             (q0 + mt * 16 + r) * row_bytes, 0);
+      // The row goes into the VECTOR offset: the hardware range check covers voffset + inst_offset only -- an SGPR
+      // offset is added unchecked -- so with the row in soffset the padded rows (>= Q) were NOT dropped but written
+      // behind the image's slab (into the next image's first rows, or behind the tensor).
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc,
+                                             voff + (uint32_t)((q0 + mt * 16 + r) * row_bytes), 0, 0);
       if (dbg & 32) asm volatile("s_nop 3" ::: "memory");
     }
   }
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(kEinsumWaves* kWave) void mask_einsum_fwd_kernel(co
     const uint32_t voff_r = (pvalid && g == 0) ? (uint32_t)(p0 * 4) : kOob;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rem[r]), out_rsrc, voff_r,
-                                             (q0 + MT * 16 + r) * row_bytes, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rem[r]), out_rsrc,
+                                             voff_r + (uint32_t)((q0 + MT * 16 + r) * row_bytes), 0, 0);
   }
 }
 
@@ -204,17 +207,12 @@ extern "C" int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out,
   int rows_per_chunk = ceil_div(Q, q_chunks);
   int MT = rows_per_chunk / 16, REM = 0;
   const int left = rows_per_chunk - MT * 16;
-  // The VALU remainder path is used for C >= 128 only.  With C = 64 (a k-loop of 4 super-steps) a few lanes of ONE
-  // main-tile store instruction per launch were lost -- the affected outputs keep the allocation's zeros, always the
-  // four lanes n, n+16, n+32, n+48 of a wave -- in about a third of the launches, only when the remainder epilogue
-  // (cross-lane sums + its 4 stores) runs after the main stores.  Found by a 200-query model test; narrowed with
-  // tools/probes/k3_grid_probe.py, k3_rem_probe.py, k3_rem_probe2.py (WM2F_K3_DBG knobs below): not the store-data
-  // hazard (wait states after every store change nothing), not a drained-vmcnt ordering issue; the same machine code
-  // is clean for C = 128 / 256 (tools/probes/k3_rem_stress.py: 0 of 200; every C = 256 test incl. the bit-exact
-  // run-to-run check at full size).  Unexplained; small C pads a row tile instead.
+  // History: with the row offset in the stores' SGPR offset (see the epilogue) padded rows were written out of bounds
+  // and, at C = 64, launches of this remainder variant lost a few lanes of one main-tile store; both are gone with
+  // the row in the vector offset (tools/probes/k3_grid_probe.py, k3_rem_probe.py, k3_rem_stress.py: clean).
   const char* e_dbg = getenv("WM2F_K3_DBG");
-  const int dbg = e_dbg ? atoi(e_dbg) : 0;  // probe knob: 1 skips the remainder FMAs, 2 the remainder epilogue, 4 forces the path for small C
-  if (left > 0 && left <= 4 && MT >= 1 && MT <= 6 && Q == q_chunks * rows_per_chunk && (C >= 128 || (dbg & 4))) REM = 4;  // exact split only
+  const int dbg = e_dbg ? atoi(e_dbg) : 0;  // probe knob: 1 skips the remainder FMAs, 2 the remainder epilogue
+  if (left > 0 && left <= 4 && MT >= 1 && MT <= 6 && Q == q_chunks * rows_per_chunk && true) REM = 4;  // exact split only
   else if (left > 0) MT += 1;
   if (MT > mt_cap) {  // fall back to plain padding with one more chunk
     q_chunks += 1;
