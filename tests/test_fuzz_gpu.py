@@ -18,3 +18,15 @@ def test_kernel_fuzz(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(seed, 10) == 0
+
+
+@pytest.mark.gpu
+def test_backward_fuzz():
+    """Backward kernels (K1, K2, point samplers, mask-loss rows) and K4 on random shapes against the oracle's autograd."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes", "fuzz_backward.py")
+    spec = importlib.util.spec_from_file_location("fuzz_backward", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(5, 6) == 0

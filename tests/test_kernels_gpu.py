@@ -329,7 +329,10 @@ def test_k2_random(ops, B, H, Q, N, D, use_mask):
 
 @pytest.mark.parametrize("B,H,Q,N,D,use_mask", [(2, 8, 100, 256, 32, True), (1, 2, 10, 37, 32, True),
                                                 (1, 4, 50, 130, 32, False), (1, 2, 30, 100, 64, True),
-                                                (1, 4, 20, 70, 16, True)])
+                                                (1, 4, 20, 70, 16, True),
+                                                # more queries than one workgroup's tiles: dK / dV sum over query chunks
+                                                # (regression: the chunks overwrote each other)
+                                                (2, 8, 200, 300, 32, True), (1, 2, 53, 283, 64, True), (1, 1, 146, 114, 16, True)])
 def test_k2_backward(ops, B, H, Q, N, D, use_mask):
     g = torch.Generator().manual_seed(17)
     E = H * D

@@ -573,7 +573,8 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ mask, const int* __restrict__ row_open, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ go, float* __restrict__ dq_ws,
-    float* __restrict__ dk, float* __restrict__ dv, int Q, int N, int heads, int n_splits, int tiles_per_split) {
+    float* __restrict__ dk, float* __restrict__ dv, int Q, int N, int heads, int n_splits, int tiles_per_split,
+    int accumulate) {
   constexpr int DK = D / 4;   // k-steps of S / dP: lane group g owns d = DK*g .. DK*g+DK-1
   constexpr int DT = D / 16;  // 16-wide d tiles
   constexpr int QL = NQT * 16;
@@ -700,8 +701,18 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bwd_kernel(
     if (key_ok) {
 #pragma unroll
       for (int i = 0; i < DT; ++i) {
-        *reinterpret_cast<f32x4*>(dv + ((int64_t)b * N + kk) * E + h * D + 16 * i + 4 * g) = dvt[i];
-        *reinterpret_cast<f32x4*>(dk + ((int64_t)b * N + kk) * E + h * D + 16 * i + 4 * g) = dkt[i];
+        float* pv = dv + ((int64_t)b * N + kk) * E + h * D + 16 * i + 4 * g;
+        float* pk = dk + ((int64_t)b * N + kk) * E + h * D + 16 * i + 4 * g;
+        if (!accumulate) {  // one query chunk covers Q: this workgroup is the only writer of its keys
+          *reinterpret_cast<f32x4*>(pv) = dvt[i];
+          *reinterpret_cast<f32x4*>(pk) = dkt[i];
+        } else {  // several query chunks (Q > NQT * 16) add into the zero-initialised gradients
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(pv + r, dvt[i][r]);
+            atomicAdd(pk + r, dkt[i][r]);
+          }
+        }
       }
     }
   }
@@ -775,11 +786,19 @@ extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v
   {                                                                                                                \
     hipLaunchKernelGGL((xattn_delta_kernel<Dv>), dim3((unsigned)ceil_div64(nrow, 256)), dim3(256), 0, st,          \
                        (const float*)out, (const float*)grad_out, delta, B, heads, Q);                             \
-    dim3 grid(n_splits* ceil_div(Q, NQTv * 16), heads, B);                                                         \
+    const int q_chunks = ceil_div(Q, NQTv * 16);                                                                   \
+    if (q_chunks > 1) { /* dK / dV are sums over the query chunks: zero them, the chunks add atomically */         \
+      const size_t kv_bytes = (size_t)B * N * heads * Dv * 4;                                                       \
+      if (hipMemsetAsync(grad_k, 0, kv_bytes, st) != hipSuccess || hipMemsetAsync(grad_v, 0, kv_bytes, st) != hipSuccess) { \
+        set_error("%s: hipMemsetAsync failed", who);                                                               \
+        return WM2F_ELAUNCH;                                                                                       \
+      }                                                                                                            \
+    }                                                                                                              \
+    dim3 grid(n_splits* q_chunks, heads, B);                                                                       \
     hipLaunchKernelGGL((masked_xattn_bwd_kernel<NQTv, Dv>), grid, dim3(kXWaves* kWave), 0, st, (const float*)q,    \
                        (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,               \
                        (const float*)lse, (const float*)delta, (const float*)grad_out, dq_ws, (float*)grad_k,      \
-                       (float*)grad_v, Q, N, heads, n_splits, tps);                                                \
+                       (float*)grad_v, Q, N, heads, n_splits, tps, q_chunks > 1 ? 1 : 0);                          \
     hipLaunchKernelGGL((xattn_dq_reduce_kernel<Dv>), dim3((unsigned)ceil_div64(nrow*(Dv / 4), 256)), dim3(256), 0, \
                        st, (const float*)dq_ws, (float*)grad_q, B, heads, Q, n_splits);                            \
   }
