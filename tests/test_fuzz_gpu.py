@@ -30,3 +30,17 @@ def test_backward_fuzz():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(5, 6) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,seed,cases", [("fuzz_model", 7, 3), ("fuzz_postprocess", 7, 8)])
+def test_model_and_postprocess_fuzz(name, seed, cases):
+    """Small random-init models (query counts, odd sizes, ragged / empty label sets) and the device post-processing on
+    random shapes against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed, cases) == 0
