@@ -20,6 +20,9 @@ SOURCES = ["api.hip", "msdeform.hip", "msdeform_tiled.hip", "msdeform_quad.hip",
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "msdeform_tiled.h"), os.path.join(os.path.dirname(HERE), "include", "wm2f.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
+# per-file flags.  masked_xattn: keep MFMA results in VGPRs -- the softmax between the two products reads S with VALU
+# instructions, and the default AGPR form cost 40 v_accvgpr moves per key tile and a register tier (120 -> 108).
+EXTRA_FLAGS = {"masked_xattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -44,8 +47,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+        if force or _stale(o, [s, os.path.abspath(__file__)] + HEADERS):
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

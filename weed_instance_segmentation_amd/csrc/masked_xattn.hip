@@ -247,6 +247,219 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_kernel(
   }
 }
 
+// Full-tile form of the kernel above for N % 16 == 0 (every feature level of a 32-divisible input): same split,
+// same tiles, same merge, but the per-tile VALU work is cut to what the arithmetic needs -- PMC at config 2 showed 7
+// VALU instructions per MFMA and 58 % of the wave cycles in s_waitcnt (profiles/r01_pmc_k2.txt):
+//   * K, V and the mask are read through buffer descriptors with a per-lane offset that never changes and the tile
+//     as a SCALAR offset (all accesses are in range by construction here; the scalar offset is not range-checked);
+//   * K, V AND the mask words of tile t+4 are issued before the arithmetic of tile t into a second register set
+//     (2x unrolled ping-pong, no copies), so no load is waited for at its use;
+//   * the softmax runs in the log2 domain (q is scaled by log2 e once): exp2 without a multiply per element;
+//   * the max over the 4 lane groups uses v_permlane16_swap / v_permlane32_swap (VALU) instead of two LDS permutes;
+//   * the file is compiled with -amdgpu-mfma-vgpr-form, which keeps S in VGPRs (40 accvgpr moves per tile gone).
+template <int NQT, int D>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, float* __restrict__ ws, int Q, int N,
+    int heads, int n_splits, int tiles_per_split) {
+  constexpr int DK = D / 4;
+  constexpr int DT = D / 16;
+  constexpr int QL = NQT * 16;
+  constexpr int RS = D + 4;
+  constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+  __shared__ __attribute__((aligned(16))) float part[kXWaves][QL][RS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile offsets stay in SGPRs
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x % n_splits, qc = blockIdx.x / n_splits;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qc * QL;
+  const int E = heads * D;
+  const float NEG_INF = -INFINITY;
+
+  float qf[NQT][DK];
+  int qrow[NQT];
+  bool use_mask[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    int qi = q0 + 16 * j + n;
+    if (qi > Q - 1) qi = Q - 1;
+    qrow[j] = qi;
+    const float* qp = q + ((int64_t)b * Q + qi) * E + h * D + DK * g;
+#pragma unroll
+    for (int t = 0; t < DK; t += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(qp + t);
+      qf[j][t] = x.x * kLog2e; qf[j][t + 1] = x.y * kLog2e; qf[j][t + 2] = x.z * kLog2e; qf[j][t + 3] = x.w * kLog2e;
+    }
+    use_mask[j] = mask != nullptr && (row_open == nullptr || row_open[(int64_t)b * Q + qi] != 0);
+  }
+
+  f32x4 o[DT][NQT];
+  float m[NQT], l[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    m[j] = NEG_INF;
+    l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int n_tiles = N / 16;
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+
+  const __amdgpu_buffer_rsrc_t k_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * N * E), 0, N * E * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * N * E), 0, N * E * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(mask != nullptr ? mask + (int64_t)b * Q * N : nullptr), 0, mask != nullptr ? Q * N : 0, 0x00020000);
+  const uint32_t k_voff = (uint32_t)((n * E + h * D + DK * g) * 4);      // K: lane (key0 + n, d = DK g + t)
+  const uint32_t v_voff = (uint32_t)((4 * g * E + h * D + n) * 4);       // V^T: lane (d = 16 i + n, key0 + 4 g + t)
+  uint32_t m_voff[NQT];                                                   // mask: 4 bytes (keys key0 + 4 g ..) of row qrow
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) m_voff[j] = (uint32_t)(qrow[j] * N + 4 * g);
+  const int row_bytes = E * 4;
+
+  struct Frag {
+    float k[DK];
+    float v[DT][4];
+    uint32_t mb[NQT];
+  };
+  auto load_tile = [&](int tile, Frag& f) __attribute__((always_inline)) {
+    if (tile > n_tiles - 1) tile = n_tiles - 1;  // the prefetch past the end re-reads a valid tile and is discarded
+    const int soff = tile * 16 * row_bytes;
+#pragma unroll
+    for (int t = 0; t < DK; t += 4) {
+      const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff + 4 * t, soff, 0));
+      f.k[t] = x[0]; f.k[t + 1] = x[1]; f.k[t + 2] = x[2]; f.k[t + 3] = x[3];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+        f.v[i][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, v_voff + 64 * i, soff + t * row_bytes, 0));
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) f.mb[j] = __builtin_amdgcn_raw_buffer_load_b32(m_rsrc, m_voff[j], tile * 16, 0);
+  };
+  // max over the 4 lane groups (rows of 16 lanes) with the gfx950 row swaps: v_permlane16_swap exchanges the odd rows
+  // of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half.
+  // Both results pass through an empty asm: this clang folds fmaxf(r[0], r[1]) of the builtin's pair into r[0]
+  // (the v_max disappears from the ISA), which the opaque copies prevent.
+  auto group_max = [&](float x) __attribute__((always_inline)) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    uint32_t a0 = a[0], a1 = a[1];
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    const float y = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    const uint32_t w = __builtin_bit_cast(uint32_t, y);
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    uint32_t c0 = c[0], c1 = c[1];
+    asm volatile("" : "+v"(c0), "+v"(c1));
+    return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+  };
+  auto compute = [&](const Frag& f) __attribute__((always_inline)) {
+    f32x4 s[NQT];
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < DK; ++t) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k[t], qf[j][t], s[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      const uint32_t mb = use_mask[j] ? f.mb[j] : 0u;
+      float tmax = NEG_INF;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[j][r] = ((mb >> (8 * r)) & 0xffu) != 0 ? NEG_INF : s[j][r];
+        tmax = fmaxf(tmax, s[j][r]);
+      }
+      tmax = group_max(tmax);
+      const float m_new = fmaxf(m[j], tmax);
+      const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m[j] - m_safe);
+      m[j] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[j][r] - m_safe);
+        s[j][r] = p;
+        psum += p;
+      }
+      l[j] = l[j] * alpha + psum;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i][j] *= alpha;
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[i][t], s[j][t], o[i][j], 0, 0, 0);
+  };
+
+  Frag fa, fb;
+  int tile = split * tiles_per_split + wave;
+  load_tile(tile, fa);
+  while (tile < t_end) {
+    load_tile(tile + kXWaves, fb);
+    compute(fa);
+    tile += kXWaves;
+    if (tile >= t_end) break;
+    load_tile(tile + kXWaves, fa);
+    compute(fb);
+    tile += kXWaves;
+  }
+
+  // ---- merge the 4 waves through LDS (m back in natural-log units; p and l are the same numbers in either base)
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    float lt = l[j];
+    lt += __shfl_xor(lt, 16, kWave);
+    lt += __shfl_xor(lt, 32, kWave);
+    float* row = &part[wave][16 * j + n][0];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(row + 16 * i + 4 * g) = o[i][j];
+    if (g == 0) {
+      row[D] = m[j] * kLn2;
+      row[D + 1] = lt;
+    }
+  }
+  __syncthreads();
+  constexpr int CH = D / 4 + 1;
+  for (int idx = threadIdx.x; idx < QL * CH; idx += kXWaves * kWave) {
+    const int ql = idx / CH, c = idx - ql * CH;
+    const int qi = q0 + ql;
+    if (qi >= Q) continue;
+    float mw[kXWaves], M = NEG_INF;
+#pragma unroll
+    for (int w = 0; w < kXWaves; ++w) {
+      mw[w] = part[w][ql][D];
+      M = fmaxf(M, mw[w]);
+    }
+    const float Ms = (M == NEG_INF) ? 0.f : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < kXWaves; ++w) {
+      const float sc = __expf(mw[w] - Ms);
+      if (c < D / 4) {
+        const float4 x = *reinterpret_cast<const float4*>(&part[w][ql][4 * c]);
+        acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w;
+      } else {
+        L += sc * part[w][ql][D + 1];
+      }
+    }
+    float* wrow = ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * RS;
+    if (c < D / 4)
+      *reinterpret_cast<float4*>(wrow + 4 * c) = acc;
+    else
+      *reinterpret_cast<float4*>(wrow + D) = make_float4(M, L, 0.f, 0.f);
+  }
+}
+
 // Query-split form of the kernel above (selectable with WM2F_K2_QSPLIT=1, not the default): the 4 waves of a workgroup walk the SAME
 // key tiles of a split and each owns NQT query tiles of its own, so K / V are fetched from L2 once per (image, head,
 // split) -- the waves' identical fragment loads meet in the CU's L1 -- while a wave still carries only NQT = 2 tiles
@@ -478,12 +691,20 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
   int nqt = ceil_div(q_tiles, q_chunks);
   hipStream_t st = (hipStream_t)stream;
   dim3 block(kXWaves * kWave);
+  // full-tile kernel: every key tile whole, 32-bit byte offsets, dword-aligned mask rows
+  const bool full = (N % 16) == 0 && (int64_t)N * heads * D * 4 < (int64_t(1) << 31) && (int64_t)Q * N < (int64_t(1) << 31) &&
+                    (reinterpret_cast<uintptr_t>(mask) & 3) == 0 && tune_env("WM2F_K2_FULL", 1) != 0;
 #define WM2F_XL(NQTv, Dv)                                                                                      \
   {                                                                                                            \
     dim3 grid(n_splits* ceil_div(Q, NQTv * 16), heads, B);                                                     \
-    hipLaunchKernelGGL((masked_xattn_fwd_kernel<NQTv, Dv>), grid, block, 0, st, (const float*)q,               \
-                       (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,           \
-                       (float*)workspace, Q, N, heads, n_splits, tps);                                         \
+    if (full)                                                                                                  \
+      hipLaunchKernelGGL((masked_xattn_fwd_full_kernel<NQTv, Dv>), grid, block, 0, st, (const float*)q,        \
+                         (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,         \
+                         (float*)workspace, Q, N, heads, n_splits, tps);                                       \
+    else                                                                                                       \
+      hipLaunchKernelGGL((masked_xattn_fwd_kernel<NQTv, Dv>), grid, block, 0, st, (const float*)q,             \
+                         (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,         \
+                         (float*)workspace, Q, N, heads, n_splits, tps);                                       \
   }
 #define WM2F_XD(Dv)                                  \
   if (nqt <= 1) WM2F_XL(1, Dv)                       \
