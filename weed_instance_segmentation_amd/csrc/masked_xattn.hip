@@ -40,7 +40,9 @@ static inline int tune_env(const char* name, int dflt) {  // experiment knobs (t
 // (image, head, split) groups: 33 / 76 / 256 us at N = 1024 / 4096 / 16384 against 57 / 110 / 375 us before.
 static inline int xattn_splits(int B, int heads, int N, bool fwd = true) {
   const int n_tiles = ceil_div(N, 16);
-  int s = ceil_div(fwd ? tune_env("WM2F_K2_WG_TARGET", 512) : 1024, B * heads);
+  // forward target re-swept with the full-tile kernel (192 ... 2048): 256 groups below 1024 key tiles (25 / 58 us at
+  // N = 1024 / 4096 against 31 / 61 with 512), 512 from there on (201 us at N = 16384 against 204)
+  int s = ceil_div(fwd ? tune_env("WM2F_K2_WG_TARGET", n_tiles >= 1024 ? 512 : 256) : 1024, B * heads);
   const int max_s = ceil_div(n_tiles, kXWaves);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
     asm volatile("" : "+v"(c0), "+v"(c1));
     return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
   };
-  auto compute = [&](const Frag& f) __attribute__((always_inline)) {
+  auto compute = [&](const Frag& f, bool live) __attribute__((always_inline)) {
     f32x4 s[NQT];
 #pragma unroll
     for (int j = 0; j < NQT; ++j) {
@@ -369,7 +371,10 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
     }
 #pragma unroll
     for (int j = 0; j < NQT; ++j) {
-      const uint32_t mb = use_mask[j] ? f.mb[j] : 0u;
+      uint32_t mb = f.mb[j];
+      asm volatile("" : "+v"(mb));  // ordered after the fences: free, the mask tests of fb were placed in compute(fa) -- behind a vmcnt(0)
+      mb = use_mask[j] ? mb : 0u;
+      mb = live ? mb : 0xffffffffu;
       float tmax = NEG_INF;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -398,19 +403,31 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
       for (int j = 0; j < NQT; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[i][t], s[j][t], o[i][j], 0, 0, 0);
+    // pin O here: otherwise these MFMAs drift below the next prefetch, the V fragments stay live across it, the
+    // prefetch lands in other registers and is copied back at the loop end -- behind a wait for the loads
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) asm volatile("" : "+v"(o[i][j]));
   };
 
   Frag fa, fb;
   int tile = split * tiles_per_split + wave;
   load_tile(tile, fa);
+  // Two tiles per iteration in ONE basic block, with scheduling fences that keep each prefetch above the arithmetic
+  // it overlaps.  With a loop exit between the halves the compiler sank the loads of fb into the block of
+  // compute(fb) and waited for them at once (half of the tiles were not prefetched); a wave with an odd tile count
+  // now runs its last half on a tile marked all-dead instead (p = 0, alpha = 1: no contribution).
   while (tile < t_end) {
     load_tile(tile + kXWaves, fb);
-    compute(fa);
-    tile += kXWaves;
-    if (tile >= t_end) break;
-    load_tile(tile + kXWaves, fa);
-    compute(fb);
-    tile += kXWaves;
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fa, true);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(tile + 2 * kXWaves, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fb, tile + kXWaves < t_end);
+    __builtin_amdgcn_sched_barrier(0);
+    tile += 2 * kXWaves;
   }
 
   // ---- merge the 4 waves through LDS (m back in natural-log units; p and l are the same numbers in either base)
