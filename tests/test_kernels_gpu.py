@@ -305,7 +305,11 @@ def test_k2_golden(ops, tag):
 @pytest.mark.parametrize("B,H,Q,N,D,use_mask", [(2, 8, 100, 1024, 32, True), (1, 8, 100, 1000, 32, True),
                                                 (2, 2, 10, 37, 32, True), (1, 4, 200, 256, 32, True),
                                                 (2, 8, 100, 512, 32, False), (1, 2, 50, 300, 64, True),
-                                                (1, 4, 20, 130, 16, True)])
+                                                (1, 4, 20, 130, 16, True),
+                                                # N % 16 == 0: the full-tile kernel, incl. waves with no tile (N = 16), odd tile
+                                                # counts per wave (the half-iteration on a dead tile) and all head sizes
+                                                (1, 4, 20, 16, 32, True), (1, 2, 130, 80, 32, True), (2, 8, 100, 208, 32, True),
+                                                (1, 2, 50, 1040, 64, True), (1, 4, 20, 144, 16, True), (1, 8, 100, 4096, 32, False)])
 def test_k2_random(ops, B, H, Q, N, D, use_mask):
     g = torch.Generator().manual_seed(7)
     E = H * D
@@ -325,6 +329,24 @@ def test_k2_random(ops, B, H, Q, N, D, use_mask):
     else:
         out = ops.masked_xattn(dev(q), dev(k), dev(v), None, None, H)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,Q,N,D", [(2, 8, 100, 1024, 32), (1, 2, 37, 80, 32), (1, 4, 130, 272, 16), (1, 2, 50, 2064, 64)])
+def test_k2_full_tile_kernel_matches_general(ops, monkeypatch, B, H, Q, N, D):
+    """The N % 16 == 0 kernel (log2-domain softmax, buffer addressing) against the general kernel on the same inputs."""
+    g = torch.Generator().manual_seed(N + Q)
+    E = H * D
+    q, k, v = dev(torch.randn(B, Q, E, generator=g) * 0.5), dev(torch.randn(B, N, E, generator=g)), dev(torch.randn(B, N, E, generator=g))
+    mask = torch.rand(B, Q, N, generator=g) < 0.8
+    mask[0, 0] = True
+    ro = dev((~mask.all(-1)).to(torch.int32))
+    m8 = dev(mask.to(torch.uint8))
+    outs = []
+    for full in ("0", "1"):
+        monkeypatch.setenv("WM2F_K2_FULL", full)
+        outs.append(ops.masked_xattn(q, k, v, m8, ro, H).clone())
+    torch.testing.assert_close(outs[1], outs[0], rtol=2e-5, atol=5e-6)
+    assert not torch.equal(outs[1], outs[0]) or N < 64  # two different kernels did run (different rounding)
 
 
 @pytest.mark.parametrize("B,H,Q,N,D,use_mask", [(2, 8, 100, 256, 32, True), (1, 2, 10, 37, 32, True),
