@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--amp", default="off", choices=["off", "bf16"])
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"])
     a = ap.parse_args()
     from transformers import Mask2FormerConfig, Mask2FormerForUniversalSegmentation, ResNetConfig
     import transformers
@@ -46,6 +47,31 @@ def main():
     missing = mine.load_state_dict(hf.state_dict(), strict=False)
     x = torch.randn(a.B, 3, a.size, a.size, device=dev)
     ctx = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if a.amp == "bf16" else (lambda: torch.autocast("cuda", enabled=False))
+    if a.mode == "train":  # full train step (loss with Hungarian matching, backward, AdamW) on bench.py's synthetic labels
+        from bench import synthetic_labels
+        ml, cl = synthetic_labels(a.B, a.size, a.size, seed=0, device=dev)
+        res = {"transformers": transformers.__version__, "torch": torch.__version__, "B": a.B, "size": a.size, "amp": a.amp, "mode": "train"}
+        for name, model in (("hf_eager", hf), ("wm2f", mine)):
+            model.train()
+            opt = torch.optim.AdamW(model.parameters(), lr=5e-5)
+            last = {}
+
+            def step():
+                with ctx():
+                    out = model(pixel_values=x, mask_labels=ml, class_labels=cl)
+                out.loss.backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                last["loss"] = out.loss.detach()
+            res[f"{name}_ms_per_step"] = round(timed(step, a.steps, a.warmup), 3)
+            res[f"{name}_last_loss"] = round(float(last["loss"]), 4)
+            res[f"{name}_images_per_s"] = round(a.B / res[f"{name}_ms_per_step"] * 1e3, 2)
+            del opt
+            model.eval()
+            torch.cuda.empty_cache()
+        res["speedup"] = round(res["hf_eager_ms_per_step"] / res["wm2f_ms_per_step"], 3)
+        print(json.dumps(res))
+        return
     with torch.no_grad(), ctx():
         o_hf = hf(pixel_values=x)
         o_me = mine(pixel_values=x)
