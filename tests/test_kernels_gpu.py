@@ -447,6 +447,14 @@ def test_fused_elementwise(ops):
         ref = torch.relu(ref) if relu else ref
         out = ops.bias_act_(dev(x.clone()), dev(bias), None if r is None else dev(r), relu)
         torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    for shape in ((2, 5, 40, 52), (1, 3, 64, 132), (2, 7, 32, 32)):  # H*W/4 >= 256: the row form (1 and 3 chunks with tails, exact fit)
+        x = torch.randn(*shape, generator=g)
+        bias, res = torch.randn(shape[1], generator=g), torch.randn(*shape, generator=g)
+        for r, relu in ((None, True), (res, True), (res, False)):
+            ref = x + bias[None, :, None, None] + (0 if r is None else r)
+            ref = torch.relu(ref) if relu else ref
+            out = ops.bias_act_(dev(x.clone()), dev(bias), None if r is None else dev(r), relu)
+            assert torch.equal(out.cpu(), ref)  # same additions in the same order
     rows, C = 77, 256
     a, b = torch.randn(2, rows, C, generator=g) * 3, torch.randn(2, rows, C, generator=g)
     gamma, beta, pos = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(rows, C, generator=g)

@@ -32,6 +32,47 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__
   }
 }
 
+// Row form for H*W/4 >= 256: a workgroup owns kBiasU * 256 float4 of ONE (image, channel) row, so the channel (and
+// the bias) is a per-workgroup scalar -- no 64-bit division per element as in the grid-stride form above -- and each
+// thread has kBiasU (x2 with a residual) 16-byte loads in flight before its first store.
+constexpr int kBiasU = 4;
+__global__ __launch_bounds__(256) void bias_act_rows_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, float* __restrict__ y, int C,
+                                                            int HW4, int chunks, int relu) {
+  const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;
+  const float b = bias[row % C];
+  const int64_t base = (int64_t)row * HW4;
+  const int i0 = ch * (256 * kBiasU) + threadIdx.x;
+  const float4* xp = reinterpret_cast<const float4*>(x) + base;
+  const float4* rp = reinterpret_cast<const float4*>(res) + base;
+  float4 v[kBiasU], r[kBiasU];
+#pragma unroll
+  for (int u = 0; u < kBiasU; ++u) {
+    const int i = i0 + u * 256;
+    v[u] = i < HW4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (res != nullptr) {
+#pragma unroll
+    for (int u = 0; u < kBiasU; ++u) {
+      const int i = i0 + u * 256;
+      r[u] = i < HW4 ? rp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kBiasU; ++u) {
+    const int i = i0 + u * 256;
+    float4 o = v[u];
+    o.x += b; o.y += b; o.z += b; o.w += b;  // same order of additions as the grid-stride form: (x + bias) + residual
+    if (res != nullptr) {
+      o.x += r[u].x; o.y += r[u].y; o.z += r[u].z; o.w += r[u].w;
+    }
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    if (i < HW4) reinterpret_cast<float4*>(y)[base + i] = o;
+  }
+}
+
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
@@ -78,6 +119,14 @@ extern "C" int wm2f_bias_act(const void* x, const void* bias, const void* residu
   WM2F_REQUIRE(N > 0 && C > 0 && HW > 0, "%s: non-positive size", who);
   WM2F_REQUIRE(HW % 4 == 0, "%s: H*W=%d must be a multiple of 4", who, HW);
   const int64_t n4 = (int64_t)N * C * (HW / 4);
+  const int HW4 = HW / 4;
+  const int chunks = ceil_div(HW4, 256 * kBiasU);
+  if (HW4 >= 256 && (int64_t)N * C * chunks < (int64_t(1) << 31)) {
+    hipLaunchKernelGGL(bias_act_rows_kernel, dim3((unsigned)((int64_t)N * C * chunks)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, (const float*)bias, (const float*)residual, (float*)y, C, HW4, chunks, relu);
+    WM2F_CHECK_LAUNCH(who);
+    return WM2F_OK;
+  }
   int64_t blocks = ceil_div64(n4, 256);
   if (blocks > 2048 * 4) blocks = 2048 * 4;  // grid-stride the rest
   hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
