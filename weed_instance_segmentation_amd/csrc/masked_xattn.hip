@@ -49,6 +49,63 @@ static inline int xattn_splits(int B, int heads, int N, bool fwd = true) {
   return s;
 }
 
+// Epilogue of the key-split kernels: the 4 waves' partial (O, m, l) of a workgroup meet in LDS, are combined and go to the
+// workspace as ONE partial per (image, head, query, split).  `m_scale` converts the running max to natural-log units
+// (1 for the general kernel, ln 2 for the log2-domain one; p and l are the same numbers in either base).
+template <int NQT, int D>
+__device__ __forceinline__ void xattn_merge_waves(float (&part)[kXWaves][NQT * 16][D + 4], const f32x4 (&o)[D / 16][NQT],
+                                                  const float (&m)[NQT], const float (&l)[NQT], float m_scale, int wave,
+                                                  int g, int n, float* __restrict__ ws, int b, int h, int heads, int Q,
+                                                  int q0, int n_splits, int split) {
+  constexpr int DT = D / 16, QL = NQT * 16, RS = D + 4;
+  const float NEG_INF = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    float lt = l[j];
+    lt += __shfl_xor(lt, 16, kWave);
+    lt += __shfl_xor(lt, 32, kWave);
+    float* row = &part[wave][16 * j + n][0];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(row + 16 * i + 4 * g) = o[i][j];
+    if (g == 0) {
+      row[D] = m[j] * m_scale;  // -inf stays -inf
+      row[D + 1] = lt;
+    }
+  }
+  __syncthreads();
+  // thread -> (query row, float4 chunk of the RS-wide row); chunk D/4 carries (m, l)
+  constexpr int CH = D / 4 + 1;
+  for (int idx = threadIdx.x; idx < QL * CH; idx += kXWaves * kWave) {
+    const int ql = idx / CH, c = idx - ql * CH;
+    const int qi = q0 + ql;
+    if (qi >= Q) continue;
+    float mw[kXWaves], M = NEG_INF;
+#pragma unroll
+    for (int w = 0; w < kXWaves; ++w) {
+      mw[w] = part[w][ql][D];
+      M = fmaxf(M, mw[w]);
+    }
+    const float Ms = (M == NEG_INF) ? 0.f : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < kXWaves; ++w) {
+      const float sc = __expf(mw[w] - Ms);
+      if (c < D / 4) {
+        const float4 x = *reinterpret_cast<const float4*>(&part[w][ql][4 * c]);
+        acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w;
+      } else {
+        L += sc * part[w][ql][D + 1];
+      }
+    }
+    float* wrow = ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * RS;
+    if (c < D / 4)
+      *reinterpret_cast<float4*>(wrow + 4 * c) = acc;
+    else
+      *reinterpret_cast<float4*>(wrow + D) = make_float4(M, L, 0.f, 0.f);
+  }
+}
+
 template <int NQT, int D>
 __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
@@ -201,52 +258,7 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_kernel(
         for (int t = 0; t < 4; ++t) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i][t], s[j][t], o[i][j], 0, 0, 0);
   }
 
-  // ---- merge the 4 waves through LDS
-#pragma unroll
-  for (int j = 0; j < NQT; ++j) {
-    float lt = l[j];
-    lt += __shfl_xor(lt, 16, kWave);
-    lt += __shfl_xor(lt, 32, kWave);
-    float* row = &part[wave][16 * j + n][0];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(row + 16 * i + 4 * g) = o[i][j];
-    if (g == 0) {
-      row[D] = m[j];
-      row[D + 1] = lt;
-    }
-  }
-  __syncthreads();
-  // thread -> (query row, float4 chunk of the RS-wide row); chunk D/4 carries (m, l)
-  constexpr int CH = D / 4 + 1;
-  for (int idx = threadIdx.x; idx < QL * CH; idx += kXWaves * kWave) {
-    const int ql = idx / CH, c = idx - ql * CH;
-    const int qi = q0 + ql;
-    if (qi >= Q) continue;
-    float mw[kXWaves], M = NEG_INF;
-#pragma unroll
-    for (int w = 0; w < kXWaves; ++w) {
-      mw[w] = part[w][ql][D];
-      M = fmaxf(M, mw[w]);
-    }
-    const float Ms = (M == NEG_INF) ? 0.f : M;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float L = 0.f;
-#pragma unroll
-    for (int w = 0; w < kXWaves; ++w) {
-      const float sc = __expf(mw[w] - Ms);
-      if (c < D / 4) {
-        const float4 x = *reinterpret_cast<const float4*>(&part[w][ql][4 * c]);
-        acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w;
-      } else {
-        L += sc * part[w][ql][D + 1];
-      }
-    }
-    float* wrow = ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * RS;
-    if (c < D / 4)
-      *reinterpret_cast<float4*>(wrow + 4 * c) = acc;
-    else
-      *reinterpret_cast<float4*>(wrow + D) = make_float4(M, L, 0.f, 0.f);
-  }
+  xattn_merge_waves<NQT, D>(part, o, m, l, 1.f, wave, g, n, ws, b, h, heads, Q, q0, n_splits, split);
 }
 
 // Full-tile form of the kernel above for N % 16 == 0 (every feature level of a 32-divisible input): same split,
@@ -430,51 +442,7 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
     tile += 2 * kXWaves;
   }
 
-  // ---- merge the 4 waves through LDS (m back in natural-log units; p and l are the same numbers in either base)
-#pragma unroll
-  for (int j = 0; j < NQT; ++j) {
-    float lt = l[j];
-    lt += __shfl_xor(lt, 16, kWave);
-    lt += __shfl_xor(lt, 32, kWave);
-    float* row = &part[wave][16 * j + n][0];
-#pragma unroll
-    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(row + 16 * i + 4 * g) = o[i][j];
-    if (g == 0) {
-      row[D] = m[j] * kLn2;
-      row[D + 1] = lt;
-    }
-  }
-  __syncthreads();
-  constexpr int CH = D / 4 + 1;
-  for (int idx = threadIdx.x; idx < QL * CH; idx += kXWaves * kWave) {
-    const int ql = idx / CH, c = idx - ql * CH;
-    const int qi = q0 + ql;
-    if (qi >= Q) continue;
-    float mw[kXWaves], M = NEG_INF;
-#pragma unroll
-    for (int w = 0; w < kXWaves; ++w) {
-      mw[w] = part[w][ql][D];
-      M = fmaxf(M, mw[w]);
-    }
-    const float Ms = (M == NEG_INF) ? 0.f : M;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float L = 0.f;
-#pragma unroll
-    for (int w = 0; w < kXWaves; ++w) {
-      const float sc = __expf(mw[w] - Ms);
-      if (c < D / 4) {
-        const float4 x = *reinterpret_cast<const float4*>(&part[w][ql][4 * c]);
-        acc.x += sc * x.x; acc.y += sc * x.y; acc.z += sc * x.z; acc.w += sc * x.w;
-      } else {
-        L += sc * part[w][ql][D + 1];
-      }
-    }
-    float* wrow = ws + ((((int64_t)b * heads + h) * Q + qi) * n_splits + split) * RS;
-    if (c < D / 4)
-      *reinterpret_cast<float4*>(wrow + 4 * c) = acc;
-    else
-      *reinterpret_cast<float4*>(wrow + D) = make_float4(M, L, 0.f, 0.f);
-  }
+  xattn_merge_waves<NQT, D>(part, o, m, l, kLn2, wave, g, n, ws, b, h, heads, Q, q0, n_splits, split);
 }
 
 // Query-split form of the kernel above (selectable with WM2F_K2_QSPLIT=1, not the default): the 4 waves of a workgroup walk the SAME
