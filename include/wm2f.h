@@ -203,6 +203,12 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
 /* wm2f_tokens_to_nchw: out (B, C, HW) = tokens (B, S, C) rows [start, start + HW) transposed per image -- the
  *                      `hidden[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` of HF:1384-1391. */
 int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int start, int HW, void* stream);
+/* wm2f_group_norm_act: y = act(GroupNorm_G(x) * gamma + beta (+ bilinear_upsample(up -> H x W))) on (B, C, H, W) fp32,
+ *                      W % 4 == 0 -- the GroupNorm tails of the FPN step, HF:1395-1405 (adapter: with `up` =
+ *                      the coarser map (B, C, Hs, Ws), align_corners = False, no ReLU; output layer: up = NULL,
+ *                      relu = 1).  stats_ws: 2 * B * G doubles of scratch.  y may alias x. */
+int wm2f_group_norm_act(const void* x, const void* gamma, const void* beta, const void* up, void* y, void* stats_ws,
+                        int B, int C, int G, int H, int W, int Hs, int Ws, float eps, int relu, void* stream);
 
 /* ---- point-sampled mask loss, batched over the prediction levels --------
  * Replaces, for all levels of a step in one launch each, the per-level tensor work of Mask2FormerLoss.loss_masks

@@ -438,6 +438,23 @@ def test_point_sample_fwd_bwd(ops):
     torch.testing.assert_close(out8, O.sample_point(u8[:, None].float(), pts)[:, 0], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,G,H,W,Hs,Ws", [(2, 64, 32, 32, 32, 16, 16), (1, 32, 8, 20, 28, 10, 14), (2, 16, 4, 9, 12, 5, 7),
+                                             (1, 256, 32, 64, 64, 32, 32), (1, 8, 2, 6, 8, 6, 8)])
+def test_group_norm_act(ops, B, C, G, H, W, Hs, Ws):
+    """The FPN tails (HF:1395-1405): GroupNorm + bilinear upsample-add, and GroupNorm + ReLU, against the stock ops."""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, C, H, W, generator=g) * 2.0 + 0.7
+    up = torch.randn(B, C, Hs, Ws, generator=g)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    F = torch.nn.functional
+    ref = F.group_norm(x, G, gamma, beta, 1e-5) + F.interpolate(up, size=(H, W), mode="bilinear", align_corners=False)
+    out = ops.group_norm_act_(dev(x.clone()), G, dev(gamma), dev(beta), 1e-5, up=dev(up))
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
+    ref2 = torch.relu(F.group_norm(x, G, gamma, beta, 1e-5))
+    out2 = ops.group_norm_act_(dev(x.clone()), G, dev(gamma), dev(beta), 1e-5, relu=True)
+    torch.testing.assert_close(out2.cpu(), ref2, rtol=2e-5, atol=2e-5)
+
+
 def test_fused_elementwise(ops):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(3, 16, 6, 10, generator=g)

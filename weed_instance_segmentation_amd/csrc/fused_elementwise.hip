@@ -190,3 +190,145 @@ extern "C" int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, 
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm tail of the FPN step (inference): HF:1395-1405 does, on the stride-4 level (B, 256, H, W),
+//     lat = GroupNorm(conv1x1(feat));  out = lat + interpolate(prev, size=(H, W), mode="bilinear");
+//     y   = ReLU(GroupNorm(conv3x3(out)))
+// As stock ops that is a normalise pass, an upsample pass (0.87 ms at config 2: 0.8 TB/s), an add and a clamp, each
+// reading and writing the 537 MB map.  Here: group statistics in one reading pass (sum and sum of squares per float4
+// chunk in fp32, accumulated across chunks in fp64), then ONE pass that normalises, adds the bilinear sample of the
+// coarser map (align_corners = False, PyTorch's source-index rule) and applies the ReLU.
+namespace wm2f {
+namespace {
+constexpr int kGnU = 4;  // float4 per thread
+
+// stats[(b * G + g) * 2 + {0, 1}] += (sum, sum of squares) of this workgroup's chunk of the group's contiguous span
+__global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int64_t span4,
+                                                          int chunks) {
+  const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;
+  const float4* xp = reinterpret_cast<const float4*>(x) + (int64_t)row * span4;
+  float s = 0.f, ss = 0.f;
+  const int64_t i0 = (int64_t)ch * (256 * kGnU) + threadIdx.x;
+  float4 v[kGnU];
+#pragma unroll
+  for (int u = 0; u < kGnU; ++u) {
+    const int64_t i = i0 + u * 256;
+    v[u] = i < span4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < kGnU; ++u) {
+    s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+  }
+  s = wave_sum64(s);
+  ss = wave_sum64(ss);
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + 2 * row, (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]);
+    atomicAdd(stats + 2 * row + 1, (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]);
+  }
+}
+
+// PyTorch's bilinear source index for align_corners = False (UpSample.h area_pixel_compute_source_index):
+// src = max(scale * (dst + 0.5) - 0.5, 0);  i0 = floor(src);  i1 = i0 + (i0 < size - 1);  lambda1 = src - i0
+struct UpIdx { int i0, i1; float l0, l1; };
+__device__ __forceinline__ UpIdx up_index(int dst, float scale, int size) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  UpIdx r;
+  r.i0 = (int)src;
+  if (r.i0 > size - 1) r.i0 = size - 1;
+  r.i1 = r.i0 + (r.i0 < size - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+// y[b][c][p] = act((x - mean) * rstd * gamma[c] + beta[c] (+ bilinear(up[b][c], p)));  a workgroup = one chunk of one (b, c) row
+__global__ __launch_bounds__(256) void group_norm_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ up, float* __restrict__ y, int C, int G,
+                                                               int H, int W, int Hs, int Ws, float eps, int relu, int chunks) {
+  const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;  // row = b * C + c
+  const int b = row / C, c = row - b * C;
+  const int cpg = C / G, g = c / cpg;
+  const int HW4 = (H * W) >> 2, W4 = W >> 2;
+  const double n = (double)cpg * (double)H * (double)W;
+  const double mean_d = stats[2 * (b * G + g)] / n;
+  double var_d = stats[2 * (b * G + g) + 1] / n - mean_d * mean_d;
+  var_d = var_d < 0.0 ? 0.0 : var_d;
+  const float rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  const float scale = rstd * gamma[c];
+  const float shift = beta[c] - (float)mean_d * scale;
+  const float4* xp = reinterpret_cast<const float4*>(x) + (int64_t)row * HW4;
+  float4* yp = reinterpret_cast<float4*>(y) + (int64_t)row * HW4;
+  const float* sp = up != nullptr ? up + (int64_t)row * Hs * Ws : nullptr;
+  const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+  const int i0 = ch * (256 * kGnU) + threadIdx.x;
+  float4 v[kGnU];
+#pragma unroll
+  for (int u = 0; u < kGnU; ++u) {
+    const int i = i0 + u * 256;
+    v[u] = i < HW4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < kGnU; ++u) {
+    const int i = i0 + u * 256;
+    if (i >= HW4) continue;
+    float o[4] = {v[u].x * scale + shift, v[u].y * scale + shift, v[u].z * scale + shift, v[u].w * scale + shift};
+    if (sp != nullptr) {
+      const int py = i / W4, px = (i - py * W4) * 4;
+      const UpIdx iy = up_index(py, sy, Hs);
+      const float* r0 = sp + (int64_t)iy.i0 * Ws;
+      const float* r1 = sp + (int64_t)iy.i1 * Ws;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const UpIdx ix = up_index(px + k, sx, Ws);
+        o[k] += iy.l0 * (ix.l0 * r0[ix.i0] + ix.l1 * r0[ix.i1]) + iy.l1 * (ix.l0 * r1[ix.i0] + ix.l1 * r1[ix.i1]);
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+    }
+    yp[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+}  // namespace
+}  // namespace wm2f
+
+extern "C" int wm2f_group_norm_act(const void* x, const void* gamma, const void* beta, const void* up, void* y,
+                                   void* stats_ws, int B, int C, int G, int H, int W, int Hs, int Ws, float eps, int relu,
+                                   void* stream) {
+  using namespace wm2f;
+  const char* who = "wm2f_group_norm_act";
+  WM2F_REQUIRE(x && gamma && beta && y && stats_ws, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && C > 0 && G > 0 && H > 0 && W > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(C % G == 0, "%s: C=%d is not a multiple of G=%d", who, C, G);
+  WM2F_REQUIRE(W % 4 == 0, "%s: W=%d must be a multiple of 4", who, W);
+  WM2F_REQUIRE(up == nullptr || (Hs > 0 && Ws > 0), "%s: the upsampled operand needs its size", who);
+  const int64_t span4 = (int64_t)(C / G) * H * W / 4;
+  const int64_t HW4 = (int64_t)H * W / 4;
+  const int64_t s_chunks = ceil_div64(span4, 256 * kGnU), a_chunks = ceil_div64(HW4, 256 * kGnU);
+  WM2F_REQUIRE((int64_t)B * G * s_chunks < (int64_t(1) << 31) && (int64_t)B * C * a_chunks < (int64_t(1) << 31) &&
+                   HW4 < (int64_t(1) << 30),
+               "%s: sizes exceed the grid limits", who);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * G, st);
+  WM2F_REQUIRE(e == hipSuccess, "%s: memset failed: %s", who, hipGetErrorString(e));
+  hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((int64_t)B * G * s_chunks)), dim3(256), 0, st, (const float*)x,
+                     (double*)stats_ws, span4, (int)s_chunks);
+  WM2F_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL(group_norm_apply_kernel, dim3((unsigned)((int64_t)B * C * a_chunks)), dim3(256), 0, st, (const float*)x,
+                     (const double*)stats_ws, (const float*)gamma, (const float*)beta, (const float*)up, (float*)y, C, G, H, W,
+                     Hs, Ws, eps, relu, (int)a_chunks);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

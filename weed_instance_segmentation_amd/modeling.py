@@ -238,9 +238,17 @@ class Mask2FormerPixelDecoder(nn.Module):
         n = self.num_fpn_levels
         for idx, feat in enumerate(features[:n][::-1]):  # HF:1395-1405
             k = n - idx
-            lat = getattr(self, f"adapter_{k}")(feat)
+            adapter, layer = getattr(self, f"adapter_{k}"), getattr(self, f"layer_{k}")
+            if fast and feat.shape[-1] % 4 == 0 and feat.dtype == torch.float32:
+                # GroupNorm + upsample-add and GroupNorm + ReLU as one statistics pass and one fused pass each
+                gn_a, gn_l = adapter[1], layer[1]
+                out = ops.group_norm_act_(adapter[0](feat), gn_a.num_groups, gn_a.weight, gn_a.bias, gn_a.eps,
+                                          up=outs[-1].contiguous())
+                outs.append(ops.group_norm_act_(layer[0](out), gn_l.num_groups, gn_l.weight, gn_l.bias, gn_l.eps, relu=True))
+                continue
+            lat = adapter(feat)
             out = lat + F.interpolate(outs[-1], size=lat.shape[-2:], mode="bilinear", align_corners=False)
-            outs.append(getattr(self, f"layer_{k}")(out))
+            outs.append(layer(out))
         return self.mask_projection(outs[-1]), outs[:3]
 
 

@@ -491,6 +491,28 @@ def tokens_to_nchw(tokens: torch.Tensor, start: int, h: int, w: int) -> torch.Te
     return out
 
 
+def group_norm_act_(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                    up: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
+    """In place: x <- act(GroupNorm(x) (+ bilinear upsample of `up` to x's size, align_corners=False)) for an NCHW map
+    (inference, no autograd) -- the GroupNorm tails of the FPN step, HF:1395-1405."""
+    if not x.is_contiguous():
+        raise ValueError("group_norm_act_: x must be NCHW-contiguous")
+    _req(x, "x")
+    gamma, beta = _req(gamma, "gamma"), _req(beta, "beta")
+    B, C, H, W = x.shape
+    Hs = Ws = 0
+    if up is not None:
+        up = _req(up, "up")
+        if up.dim() != 4 or up.shape[:2] != x.shape[:2]:
+            raise ValueError("group_norm_act_: up must be (B, C, Hs, Ws)")
+        Hs, Ws = int(up.shape[2]), int(up.shape[3])
+    ws = torch.empty(2 * B * groups, device=x.device, dtype=torch.float64)
+    with torch.cuda.device(x.device):
+        check(load().wm2f_group_norm_act(_p(x), _p(gamma), _p(beta), _p(up), _p(x), _p(ws), B, C, int(groups), H, W, Hs, Ws,
+                                         float(eps), 1 if relu else 0, _stream(x)), "wm2f_group_norm_act")
+    return x
+
+
 # ------------------------------------------------------------------ instance post-processing (SURVEY 8f rank 2)
 _GRID = (384, 384)  # the dependency's hard-coded intermediate size (image_processing_mask2former.py:680-682)
 
