@@ -203,6 +203,16 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
 /* wm2f_tokens_to_nchw: out (B, C, HW) = tokens (B, S, C) rows [start, start + HW) transposed per image -- the
  *                      `hidden[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` of HF:1384-1391. */
 int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int start, int HW, void* stream);
+/* wm2f_group_norm_tokens: tokens[b][start + p][c] = GroupNorm_G(x + bias)[b][c][p] * gamma + beta for x (B, C, HW) fp32,
+ *                         bias (C) or NULL, tokens (B, S, C) -- one level's input projection of the pixel decoder
+ *                         (HF:1341-1357: Conv2d 1x1 [+ bias] + GroupNorm, flatten(2).transpose(1, 2), cat over levels)
+ *                         written into its rows of the token buffer.  stats_ws: 2 * B * G doubles of scratch. */
+int wm2f_group_norm_tokens(const void* x, const void* bias, const void* gamma, const void* beta, void* tokens,
+                           void* stats_ws, int B, int C, int G, int HW, int S, int start, float eps, void* stream);
+/* wm2f_bias_relu_maxpool: y (N, C, H/2, W/2) = MaxPool2d(kernel 3, stride 2, padding 1)(ReLU(x + bias[c])), x (N, C, H, W)
+ *                         fp32, H even, W % 8 == 0 -- the stem of transformers' ResNet embeddings
+ *                         (modeling_resnet.py ResNetEmbeddings: convolution, normalization folded, ReLU, pooler). */
+int wm2f_bias_relu_maxpool(const void* x, const void* bias, void* y, int N, int C, int H, int W, void* stream);
 /* wm2f_group_norm_act: y = act(GroupNorm_G(x) * gamma + beta (+ bilinear_upsample(up -> H x W))) on (B, C, H, W) fp32,
  *                      W % 4 == 0 -- the GroupNorm tails of the FPN step, HF:1395-1405 (adapter: with `up` =
  *                      the coarser map (B, C, Hs, Ws), align_corners = False, no ReLU; output layer: up = NULL,

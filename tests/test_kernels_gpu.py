@@ -455,6 +455,33 @@ def test_group_norm_act(ops, B, C, G, H, W, Hs, Ws):
     torch.testing.assert_close(out2.cpu(), ref2, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,C,G,H,W,use_bias", [(2, 64, 32, 8, 8, True), (1, 256, 32, 20, 28, True), (2, 48, 4, 6, 10, False),
+                                                (1, 40, 8, 3, 4, True)])
+def test_group_norm_tokens(ops, B, C, G, H, W, use_bias):
+    """Input projection tail (HF:1341-1357): bias + GroupNorm written transposed into its rows of the token buffer."""
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    bias = torch.randn(C, generator=g) if use_bias else None
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xb = x + (bias[None, :, None, None] if use_bias else 0)
+    ref = torch.nn.functional.group_norm(xb, G, gamma, beta, 1e-5).flatten(2).transpose(1, 2)
+    S, start = H * W + 13, 5
+    tokens = torch.full((B, S, C), 7.0)
+    out = ops.group_norm_tokens_(dev(x), None if bias is None else dev(bias), G, dev(gamma), dev(beta), 1e-5, dev(tokens), start).cpu()
+    torch.testing.assert_close(out[:, start:start + H * W], ref, rtol=2e-5, atol=2e-5)
+    assert bool((out[:, :start] == 7.0).all()) and bool((out[:, start + H * W:] == 7.0).all())  # other rows untouched
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 16, 24), (1, 3, 2, 8), (2, 64, 64, 64), (1, 7, 30, 40)])
+def test_bias_relu_maxpool(ops, N, C, H, W):
+    """ResNet stem tail: MaxPool2d(3, 2, 1)(ReLU(x + bias)) in one pass == the stock ops, bit for bit (max and add commute)."""
+    g = torch.Generator().manual_seed(H + W)
+    x, bias = torch.randn(N, C, H, W, generator=g), torch.randn(C, generator=g)
+    ref = torch.nn.functional.max_pool2d(torch.relu(x + bias[None, :, None, None]), 3, 2, 1)
+    out = ops.bias_relu_maxpool(dev(x), dev(bias))
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
+
+
 def test_fused_elementwise(ops):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(3, 16, 6, 10, generator=g)

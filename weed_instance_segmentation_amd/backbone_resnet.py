@@ -124,7 +124,17 @@ class _Embedder(nn.Module):
         self.pooler = nn.MaxPool2d(3, 2, 1)
 
     def forward(self, x):
-        return self.pooler(self.embedder(x))
+        e, pool = self.embedder, self.pooler
+        if (not e.training and _fused_ok(x) and isinstance(e.activation, nn.ReLU)
+                and (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False)):
+            # inference: bias + ReLU + 3x3 / 2 max pool in one pass over the raw convolution output
+            c = e.convolution
+            w, b = _folded(c, e.normalization, e._fold)
+            y = torch.nn.functional.conv2d(x, w, None, c.stride, c.padding)
+            if y.shape[-2] % 2 == 0 and y.shape[-1] % 8 == 0:
+                return ops.bias_relu_maxpool(y, b)
+            return pool(torch.relu_(y.add_(b[None, :, None, None])))
+        return pool(e(x))
 
 
 class _Encoder(nn.Module):

@@ -204,9 +204,11 @@ namespace {
 constexpr int kGnU = 4;  // float4 per thread
 
 // stats[(b * G + g) * 2 + {0, 1}] += (sum, sum of squares) of this workgroup's chunk of the group's contiguous span
-__global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int64_t span4,
-                                                          int chunks) {
-  const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;
+// `bias` (nullable, per channel) is added to x first: the statistics of conv(x) + bias without a separate bias pass.
+__global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                          double* __restrict__ stats, int64_t span4, int chunks, int G, int cpg,
+                                                          int HW4) {
+  const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;  // row = b * G + g
   const float4* xp = reinterpret_cast<const float4*>(x) + (int64_t)row * span4;
   float s = 0.f, ss = 0.f;
   const int64_t i0 = (int64_t)ch * (256 * kGnU) + threadIdx.x;
@@ -215,6 +217,10 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
   for (int u = 0; u < kGnU; ++u) {
     const int64_t i = i0 + u * 256;
     v[u] = i < span4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr && i < span4) {
+      const float bb = bias[(row % G) * cpg + (int)(i / HW4)];
+      v[u].x += bb; v[u].y += bb; v[u].z += bb; v[u].w += bb;
+    }
   }
 #pragma unroll
   for (int u = 0; u < kGnU; ++u) {
@@ -301,6 +307,49 @@ __global__ __launch_bounds__(256) void group_norm_apply_kernel(const float* __re
     yp[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
+
+// tokens[b][start + p][c] = GroupNorm(x + bias)[b][c][p]: the input projections of the pixel decoder (HF:1341-1357:
+// Conv2d 1x1 + GroupNorm per level, then flatten(2).transpose(1, 2) and a concatenation over levels) written straight
+// into the (B, S, C) token buffer.  32 x 32 LDS tile transpose, both sides coalesced.
+__global__ __launch_bounds__(256) void group_norm_tokens_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ tok, int C, int G,
+                                                                int HW, int S, int start, float eps) {
+  __shared__ float tile[32][33];
+  __shared__ float sc[32], sh[32];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int cpg = C / G;
+  if (threadIdx.x < 32) {
+    const int c = c0 + threadIdx.x;
+    float scale = 0.f, shift = 0.f;
+    if (c < C) {
+      const int g = c / cpg;
+      const double n = (double)cpg * (double)HW;
+      const double mean_d = stats[2 * (b * G + g)] / n;
+      double var_d = stats[2 * (b * G + g) + 1] / n - mean_d * mean_d;
+      var_d = var_d < 0.0 ? 0.0 : var_d;
+      scale = (float)(1.0 / sqrt(var_d + (double)eps)) * gamma[c];
+      shift = beta[c] + ((bias != nullptr ? bias[c] : 0.f) - (float)mean_d) * scale;
+    }
+    sc[threadIdx.x] = scale;
+    sh[threadIdx.x] = shift;
+  }
+  __syncthreads();
+  const float* src = x + (int64_t)b * C * HW;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int c = c0 + ty + r, p = p0 + tx;
+    tile[ty + r][tx] = (c < C && p < HW) ? src[(int64_t)c * HW + p] * sc[ty + r] + sh[ty + r] : 0.f;
+  }
+  __syncthreads();
+  float* dst = tok + ((int64_t)b * S + start) * C;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int p = p0 + ty + r, c = c0 + tx;
+    if (p < HW && c < C) dst[(int64_t)p * C + c] = tile[tx][ty + r];
+  }
+}
 }  // namespace
 }  // namespace wm2f
 
@@ -324,11 +373,90 @@ extern "C" int wm2f_group_norm_act(const void* x, const void* gamma, const void*
   hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * G, st);
   WM2F_REQUIRE(e == hipSuccess, "%s: memset failed: %s", who, hipGetErrorString(e));
   hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((int64_t)B * G * s_chunks)), dim3(256), 0, st, (const float*)x,
-                     (double*)stats_ws, span4, (int)s_chunks);
+                     (const float*)nullptr, (double*)stats_ws, span4, (int)s_chunks, G, C / G, (int)HW4);
   WM2F_CHECK_LAUNCH(who);
   hipLaunchKernelGGL(group_norm_apply_kernel, dim3((unsigned)((int64_t)B * C * a_chunks)), dim3(256), 0, st, (const float*)x,
                      (const double*)stats_ws, (const float*)gamma, (const float*)beta, (const float*)up, (float*)y, C, G, H, W,
                      Hs, Ws, eps, relu, (int)a_chunks);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_group_norm_tokens(const void* x, const void* bias, const void* gamma, const void* beta, void* tokens,
+                                      void* stats_ws, int B, int C, int G, int HW, int S, int start, float eps, void* stream) {
+  using namespace wm2f;
+  const char* who = "wm2f_group_norm_tokens";
+  WM2F_REQUIRE(x && gamma && beta && tokens && stats_ws, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && B < 65536 && C > 0 && G > 0 && HW > 0 && S > 0, "%s: bad size", who);
+  WM2F_REQUIRE(C % G == 0, "%s: C=%d is not a multiple of G=%d", who, C, G);
+  WM2F_REQUIRE(HW % 4 == 0, "%s: H*W=%d must be a multiple of 4", who, HW);
+  WM2F_REQUIRE(start >= 0 && (int64_t)start + HW <= S, "%s: rows [%d, %d) leave the token buffer of %d rows", who, start,
+               start + HW, S);
+  const int64_t span4 = (int64_t)(C / G) * HW / 4;
+  const int64_t s_chunks = ceil_div64(span4, 256 * kGnU);
+  WM2F_REQUIRE((int64_t)B * G * s_chunks < (int64_t(1) << 31) && ceil_div(C, 32) < 65536 && span4 < (int64_t(1) << 31),
+               "%s: sizes exceed the grid limits", who);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * G, st);
+  WM2F_REQUIRE(e == hipSuccess, "%s: memset failed: %s", who, hipGetErrorString(e));
+  hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((int64_t)B * G * s_chunks)), dim3(256), 0, st, (const float*)x,
+                     (const float*)bias, (double*)stats_ws, span4, (int)s_chunks, G, C / G, HW / 4);
+  WM2F_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL(group_norm_tokens_kernel, dim3(ceil_div(HW, 32), ceil_div(C, 32), B), dim3(256), 0, st, (const float*)x,
+                     (const float*)bias, (const double*)stats_ws, (const float*)gamma, (const float*)beta, (float*)tokens, C, G,
+                     HW, S, start, eps);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stem tail of the ResNet backbone (inference): y = MaxPool2d(3, stride 2, pad 1)(ReLU(x + bias[c])) in one pass.
+// As two passes the full-resolution map (537 MB at config 2) is written and read back; max commutes with the monotone
+// bias + ReLU, so the pool runs on the raw convolution output and the epilogue on the quarter-size result.
+// H, W even, W % 8 == 0: a thread produces 4 adjacent outputs from 3 rows of (1 + 8) inputs (two aligned float4 and
+// the left neighbour); rows above / left of the map count as -inf, exactly as PyTorch pads.
+namespace wm2f {
+namespace {
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int C, int H, int W, int64_t total4) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const int OW4 = W >> 3, OH = H >> 1;
+  const int ox4 = (int)(t % OW4);
+  const int64_t r = t / OW4;
+  const int oy = (int)(r % OH);
+  const int64_t nc = r / OH;
+  const float* xp = x + nc * H * W + (int64_t)(8 * ox4);
+  const float NEG = -INFINITY;
+  float m[4] = {NEG, NEG, NEG, NEG};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int iy = 2 * oy - 1 + k;
+    if (iy < 0) continue;  // iy <= H - 1 always (H even)
+    const float* row = xp + (int64_t)iy * W;
+    const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+    const float left = ox4 > 0 ? row[-1] : NEG;
+    m[0] = fmaxf(m[0], fmaxf(left, fmaxf(a.x, a.y)));
+    m[1] = fmaxf(m[1], fmaxf(a.y, fmaxf(a.z, a.w)));
+    m[2] = fmaxf(m[2], fmaxf(a.w, fmaxf(b.x, b.y)));
+    m[3] = fmaxf(m[3], fmaxf(b.y, fmaxf(b.z, b.w)));
+  }
+  const float bb = bias[(int)(nc % C)];
+  reinterpret_cast<float4*>(y)[t] = make_float4(fmaxf(m[0] + bb, 0.f), fmaxf(m[1] + bb, 0.f), fmaxf(m[2] + bb, 0.f), fmaxf(m[3] + bb, 0.f));
+}
+}  // namespace
+}  // namespace wm2f
+
+extern "C" int wm2f_bias_relu_maxpool(const void* x, const void* bias, void* y, int N, int C, int H, int W, void* stream) {
+  using namespace wm2f;
+  const char* who = "wm2f_bias_relu_maxpool";
+  WM2F_REQUIRE(x && bias && y, "%s: null pointer", who);
+  WM2F_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(H % 2 == 0 && W % 8 == 0, "%s: needs H even and W %% 8 == 0 (got %d x %d)", who, H, W);
+  const int64_t total4 = (int64_t)N * C * (H / 2) * (W / 8);
+  WM2F_REQUIRE(ceil_div64(total4, 256) < (int64_t(1) << 31), "%s: sizes exceed the grid limits", who);
+  hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x, (const float*)bias, (float*)y, C, H, W, total4);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }

@@ -214,19 +214,31 @@ class Mask2FormerPixelDecoder(nn.Module):
 
     def forward(self, features: Sequence[torch.Tensor]):
         d = self.config.feature_size
-        embeds, poss = [], []
-        for lvl, x in enumerate(features[::-1][:3]):
-            embeds.append(self.input_projections[lvl](x))
+        levels = features[::-1][:3]
+        level_hw = [(int(x.shape[2]), int(x.shape[3])) for x in levels]
+        B = levels[0].shape[0]
+        fast = (not torch.is_grad_enabled() and levels[0].is_cuda and all(x.dtype == torch.float32 for x in levels)
+                and not torch.is_autocast_enabled("cuda"))
+        poss = []
+        for lvl, x in enumerate(levels):
             pe = sine_position_embedding(x.shape[2], x.shape[3], d // 2, x.device, x.dtype)
             poss.append(pe.flatten(1).transpose(0, 1) + self.level_embed[lvl][None, :])  # (HW, C)
-        level_hw = [(int(e.shape[2]), int(e.shape[3])) for e in embeds]
-        B = embeds[0].shape[0]
-        hidden = torch.cat([e.flatten(2).transpose(1, 2) for e in embeds], 1)
+        if fast and all((h * w) % 4 == 0 for h, w in level_hw):
+            # 1x1 convolution, then bias + GroupNorm + transpose written straight into the token buffer (one pass for
+            # the statistics, one for the tokens) instead of bias add, GroupNorm, strided flatten and concatenation
+            hidden = torch.empty(B, sum(h * w for h, w in level_hw), d, device=levels[0].device, dtype=torch.float32)
+            start = 0
+            for lvl, x in enumerate(levels):
+                conv, gn = self.input_projections[lvl]
+                raw = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                ops.group_norm_tokens_(raw, conv.bias, gn.num_groups, gn.weight, gn.bias, gn.eps, hidden, start)
+                start += level_hw[lvl][0] * level_hw[lvl][1]
+        else:
+            embeds = [self.input_projections[lvl](x) for lvl, x in enumerate(levels)]
+            hidden = torch.cat([e.flatten(2).transpose(1, 2) for e in embeds], 1)
         pos = torch.cat(poss, 0).contiguous()  # (S, C): identical for every image of the batch
         hidden = self.encoder(hidden, pos, level_hw)
         outs, tokens, start = [], [], 0
-        fast = (not torch.is_grad_enabled() and hidden.is_cuda and hidden.dtype == torch.float32
-                and not torch.is_autocast_enabled("cuda"))
         for h, w in level_hw:
             tokens.append(hidden[:, start:start + h * w])  # (B, hw, C) views: what the transformer decoder consumes
             if fast:  # tiled transpose instead of a generic strided copy (0.9 ms -> <0.1 ms for the finest level)

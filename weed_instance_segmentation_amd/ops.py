@@ -491,6 +491,38 @@ def tokens_to_nchw(tokens: torch.Tensor, start: int, h: int, w: int) -> torch.Te
     return out
 
 
+def group_norm_tokens_(x: torch.Tensor, bias: torch.Tensor | None, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                       tokens: torch.Tensor, start: int) -> torch.Tensor:
+    """tokens[:, start:start+H*W, :] <- GroupNorm(x + bias) in token layout, for x (B, C, H, W) and tokens (B, S, C)
+    (inference, no autograd): one level's input projection of the pixel decoder, HF:1341-1357."""
+    if not x.is_contiguous() or not tokens.is_contiguous():
+        raise ValueError("group_norm_tokens_: x and tokens must be contiguous")
+    _req(x, "x"), _req(tokens, "tokens")
+    gamma, beta = _req(gamma, "gamma"), _req(beta, "beta")
+    if bias is not None:
+        bias = _req(bias, "bias")
+    B, C, H, W = x.shape
+    if tokens.dim() != 3 or tokens.shape[0] != B or tokens.shape[2] != C:
+        raise ValueError("group_norm_tokens_: tokens must be (B, S, C)")
+    ws = torch.empty(2 * B * groups, device=x.device, dtype=torch.float64)
+    with torch.cuda.device(x.device):
+        check(load().wm2f_group_norm_tokens(_p(x), _p(bias), _p(gamma), _p(beta), _p(tokens), _p(ws), B, C, int(groups), H * W,
+                                            int(tokens.shape[1]), int(start), float(eps), _stream(x)), "wm2f_group_norm_tokens")
+    return tokens
+
+
+def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """MaxPool2d(3, 2, 1)(ReLU(x + bias[c])) of an NCHW map in one pass (inference, no autograd): the ResNet stem tail."""
+    if not x.is_contiguous():
+        raise ValueError("bias_relu_maxpool: x must be NCHW-contiguous")
+    _req(x, "x"), _req(bias, "bias")
+    N, C, H, W = x.shape
+    y = torch.empty(N, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(load().wm2f_bias_relu_maxpool(_p(x), _p(bias), _p(y), N, C, H, W, _stream(x)), "wm2f_bias_relu_maxpool")
+    return y
+
+
 def group_norm_act_(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
                     up: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
     """In place: x <- act(GroupNorm(x) (+ bilinear upsample of `up` to x's size, align_corners=False)) for an NCHW map
