@@ -48,8 +48,6 @@ struct QuadGeom {
   int a_qstride, b_qstride;
 };
 
-__device__ const float4 g_zero_px[1] = {{0.f, 0.f, 0.f, 0.f}};
-
 // MODE 7 (variant 73): the kernel with in-kernel time stamps (s_memtime, wave 0 of each workgroup),
 // read back with wm2f_debug_stamps.  A profiling aid; no other mode touches this buffer.
 constexpr int kStampSlots = 16, kStampGroups = 8192;

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
   constexpr int D = 32, kWaves = kBwdThreads / kWave, NP = NL * P;
   static_assert(NP <= 64, "one lane per sampling point");
   extern __shared__ __attribute__((aligned(16))) float4 win[];
-  float* winf = reinterpret_cast<float*>(win);
   const int id = xcd_contiguous_id(blockIdx.x, per_xcd);
   if (id >= n_logical) return;
   int* lv_tab = reinterpret_cast<int*>(win + g.lv_tab_off4);
