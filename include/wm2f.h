@@ -209,6 +209,10 @@ int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int 
  *                         written into its rows of the token buffer.  stats_ws: 2 * B * G doubles of scratch. */
 int wm2f_group_norm_tokens(const void* x, const void* bias, const void* gamma, const void* beta, void* tokens,
                            void* stats_ws, int B, int C, int G, int HW, int S, int start, float eps, void* stream);
+/* wm2f_resize_bilinear: y (NC, Ho, Wo) = torch.nn.functional.interpolate(x (NC, H, W), size=(Ho, Wo), mode="bilinear",
+ *                       align_corners=False) in fp32, Wo % 4 == 0 -- the resize of HF:2048-2050, applied to the mask
+ *                       FEATURES once per level instead of to every layer's logits (resize and einsum commute). */
+int wm2f_resize_bilinear(const void* x, void* y, int NC, int H, int W, int Ho, int Wo, void* stream);
 /* wm2f_bias_relu_maxpool: y (N, C, H/2, W/2) = MaxPool2d(kernel 3, stride 2, padding 1)(ReLU(x + bias[c])), x (N, C, H, W)
  *                         fp32, H even, W % 8 == 0 -- the stem of transformers' ResNet embeddings
  *                         (modeling_resnet.py ResNetEmbeddings: convolution, normalization folded, ReLU, pooler). */

@@ -472,6 +472,15 @@ def test_group_norm_tokens(ops, B, C, G, H, W, use_bias):
     assert bool((out[:, :start] == 7.0).all()) and bool((out[:, start + H * W:] == 7.0).all())  # other rows untouched
 
 
+@pytest.mark.parametrize("N,C,H,W,Ho,Wo", [(2, 5, 64, 64, 8, 8), (1, 3, 50, 84, 13, 20), (2, 4, 16, 16, 16, 16), (1, 2, 9, 12, 18, 24),
+                                           (1, 6, 256, 256, 32, 32)])
+def test_resize_bilinear(ops, N, C, H, W, Ho, Wo):
+    """Down / identity / up: == F.interpolate(mode="bilinear", align_corners=False)."""
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(H + Wo))
+    ref = torch.nn.functional.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    torch.testing.assert_close(ops.resize_bilinear(dev(x), (Ho, Wo)).cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 5, 16, 24), (1, 3, 2, 8), (2, 64, 64, 64), (1, 7, 30, 40)])
 def test_bias_relu_maxpool(ops, N, C, H, W):
     """ResNet stem tail: MaxPool2d(3, 2, 1)(ReLU(x + bias)) in one pass == the stock ops, bit for bit (max and add commute)."""

@@ -172,6 +172,33 @@ def test_forward_dim256_fused_inference_paths():
         assert err < 1e-3, err
 
 
+def test_low_resolution_attention_masks_equal_full_resolution_route(tiny):
+    """Inference without auxiliary outputs builds the attention masks from mask features resized once per level
+    (resize(einsum(E, P)) == einsum(E, resize(P))): same final predictions as the full-resolution route, and as the golden."""
+    g, cfg, model, _ = tiny
+    dec = model.model.transformer_module.decoder
+    x = T(g["pixel_values"]).cuda()
+    outs = {}
+    try:
+        for low in (True, False):
+            dec.low_res_masks = low
+            with torch.no_grad():
+                o = model(pixel_values=x)
+            assert o.auxiliary_logits is None
+            outs[low] = (o.masks_queries_logits.cpu(), o.class_queries_logits.cpu())
+    finally:
+        dec.low_res_masks = True
+    ref = T(g["masks_queries_logits"])
+    for low in (True, False):
+        assert (outs[low][0] - ref).abs().max().item() / ref.abs().max().item() < 1e-3
+        torch.testing.assert_close(outs[low][1], T(g["class_queries_logits"]), rtol=1e-3, atol=1e-3)
+    assert (outs[True][0] - outs[False][0]).abs().max().item() / ref.abs().max().item() < 1e-3
+    # with auxiliary outputs requested every prediction is computed at full resolution again
+    with torch.no_grad():
+        o = model(pixel_values=x, output_auxiliary_logits=True)
+    assert all(a["masks_queries_logits"] is not None for a in o.auxiliary_logits)
+
+
 def test_bf16_autocast_forward_and_train_step(tiny):
     """BASELINE configs 3-5 run under bf16 autocast.  Stock ops follow PyTorch's autocast policy; the wm2f kernels take
     the fp32 policy (inputs cast to fp32, as grid_sample / softmax get in the dependency).  Checked against the fp32

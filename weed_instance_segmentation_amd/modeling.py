@@ -385,6 +385,15 @@ class MaskPredictor(nn.Module):
         mask, row_open = ops.attn_mask_build(logits, next_size)
         return logits, mask, row_open
 
+    def attention_mask_only(self, h_norm, pix_level, size):
+        """The attention mask of the next layer WITHOUT the full-resolution logits (inference, when no caller sees the
+        intermediate predictions).  HF:2046-2054 computes einsum(E, P) at the mask-feature resolution and resizes it
+        bilinearly to the level's size; both are linear, so resize(einsum(E, P)) == einsum(E, resize(P)): `pix_level` is
+        the mask-feature map resized ONCE per forward to this level's size, and the einsum runs on 1/64 ... 1/4 of the
+        pixels.  The values differ from the full-resolution route by fp32 rounding only."""
+        logits = ops.mask_einsum(self.mask_embedder(h_norm), pix_level, tag=f"hw{size[0] * size[1]}")
+        return ops.attn_mask_build(logits, size)  # same size in and out: the bilinear resize inside is the identity
+
 
 class MaskedAttentionDecoder(nn.Module):
     """HF:1801-1960."""
@@ -396,8 +405,13 @@ class MaskedAttentionDecoder(nn.Module):
         self.layers = nn.ModuleList([MaskedAttentionDecoderLayer(config) for _ in range(config.decoder_layers - 1)])
         self.layernorm = nn.LayerNorm(config.hidden_dim)
         self.mask_predictor = MaskPredictor(config.hidden_dim, config.num_attention_heads, config.mask_feature_size)
+        # switch for A/B tests of the low-resolution attention-mask route (WM2F_LOW_RES_MASKS=0 turns it off at construction)
+        self.low_res_masks = os.environ.get("WM2F_LOW_RES_MASKS", "1") != "0"
 
-    def forward(self, h, qpos, feats, poss, mask_features, sizes):
+    def forward(self, h, qpos, feats, poss, mask_features, sizes, need_all_logits=True):
+        """need_all_logits=False (inference without auxiliary outputs): only the LAST prediction is computed at the
+        mask-feature resolution; the earlier ones only feed the next layer's attention mask and run at that level's
+        resolution (MaskPredictor.attention_mask_only).  `all_logits[:-1]` is then None."""
         pix_t = None
         if (mask_features.dtype == torch.bfloat16 and mask_features.is_cuda and mask_features.shape[1] % 32 == 0
                 and mask_features.shape[1] <= 512):
@@ -405,8 +419,16 @@ class MaskedAttentionDecoder(nn.Module):
             pix_t = ops.nchw_to_pixel_major_bf16(mask_features.contiguous())
         elif mask_features.dtype != torch.float32:
             mask_features = mask_features.float()  # once, not once per mask-predictor call
+        low = (not need_all_logits and self.low_res_masks and not torch.is_grad_enabled() and pix_t is None
+               and mask_features.is_cuda and mask_features.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
+               and all(ww % 4 == 0 for hh, ww in sizes))
+        pix_level = [ops.resize_bilinear(mask_features.contiguous(), s) for s in sizes] if low else None
         inter = [self.layernorm(h)]
-        logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0], pix_t)
+        if low:
+            logits = None
+            mask, row_open = self.mask_predictor.attention_mask_only(inter[0], pix_level[0], sizes[0])
+        else:
+            logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0], pix_t)
         all_logits = [logits]
         keys_in = [None, None, None]  # feats[lvl] + poss[lvl]: the same for the three layers that attend to a level
         for idx, layer in enumerate(self.layers):
@@ -418,7 +440,14 @@ class MaskedAttentionDecoder(nn.Module):
             k, v = layer.cross_attn.project_kv(keys_in[lvl], feats[lvl])
             h = layer(h, qpos, k, v, mask, row_open)
             inter.append(self.layernorm(h))
-            logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[(idx + 1) % 3], pix_t)
+            nxt = (idx + 1) % 3
+            if low and idx + 1 < len(self.layers):
+                logits = None
+                mask, row_open = self.mask_predictor.attention_mask_only(inter[-1], pix_level[nxt], sizes[nxt])
+            elif low:  # the prediction that is returned: full resolution, and no layer left to mask
+                logits = ops.mask_einsum(self.mask_predictor.mask_embedder(inter[-1]), mask_features)
+            else:
+                logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[nxt], pix_t)
             all_logits.append(logits)
         return h, inter, all_logits
 
@@ -440,7 +469,7 @@ class Mask2FormerTransformerModule(nn.Module):
         self.decoder = MaskedAttentionDecoder(config)
         self.level_embed = nn.Embedding(3, d)
 
-    def forward(self, multi_scale, mask_features, tokens=None):
+    def forward(self, multi_scale, mask_features, tokens=None, need_all_logits=True):
         """tokens: optional (B, hw, C) token-layout views of `multi_scale` (saves re-flattening the NCHW maps)."""
         d = self.config.hidden_dim
         B = mask_features.shape[0]
@@ -454,7 +483,7 @@ class Mask2FormerTransformerModule(nn.Module):
             feats.append(tok + self.level_embed.weight[i][None, None, :])  # (B, HW, C)
         qpos = self.queries_embedder.weight[None].expand(B, -1, -1)
         h = self.queries_features.weight[None].expand(B, -1, -1)
-        return self.decoder(h, qpos, feats, poss, mask_features, sizes)
+        return self.decoder(h, qpos, feats, poss, mask_features, sizes, need_all_logits=need_all_logits)
 
 
 class Mask2FormerModel(nn.Module):
@@ -547,11 +576,15 @@ class Mask2FormerForUniversalSegmentation(nn.Module):
                 point_provider=None, **kwargs):
         if output_attentions:
             raise NotImplementedError("output_attentions: attention maps are never materialised by the kernels")
+        want_aux = self.config.output_auxiliary_logits if output_auxiliary_logits is None else output_auxiliary_logits
+        with_loss = mask_labels is not None and class_labels is not None
         feats, mask_features, multi_scale = self.model.pixel_level_module(pixel_values)
         h, inter, all_logits = self.model.transformer_module(multi_scale, mask_features,
-                                                             tokens=self.model.pixel_level_module.last_tokens())
+                                                             tokens=self.model.pixel_level_module.last_tokens(),
+                                                             need_all_logits=bool(want_aux or with_loss))
         all_classes = [self.class_predictor(s) for s in inter]
-        aux = [{"masks_queries_logits": m, "class_queries_logits": c} for m, c in zip(all_logits[:-1], all_classes[:-1])]
+        aux = ([{"masks_queries_logits": m, "class_queries_logits": c} for m, c in zip(all_logits[:-1], all_classes[:-1])]
+               if want_aux else None)
         loss = loss_dict = indices = None
         if mask_labels is not None and class_labels is not None:
             use_aux = self.config.use_auxiliary_loss
@@ -559,10 +592,9 @@ class Mask2FormerForUniversalSegmentation(nn.Module):
                                                 all_classes if use_aux else all_classes[-1:], mask_labels, class_labels,
                                                 point_provider=point_provider)
             loss = sum(loss_dict.values())
-        want_aux = self.config.output_auxiliary_logits if output_auxiliary_logits is None else output_auxiliary_logits
         out = Mask2FormerForUniversalSegmentationOutput(
             loss=loss, class_queries_logits=all_classes[-1], masks_queries_logits=all_logits[-1],
-            auxiliary_logits=aux if want_aux else None, encoder_last_hidden_state=feats[-1],
+            auxiliary_logits=aux, encoder_last_hidden_state=feats[-1],
             pixel_decoder_last_hidden_state=mask_features, transformer_decoder_last_hidden_state=h,
             encoder_hidden_states=tuple(feats) if output_hidden_states else None,
             pixel_decoder_hidden_states=tuple(multi_scale) if output_hidden_states else None,

@@ -193,7 +193,7 @@ def ms_deform_attn_variant(value, level_hw, a, b, ref=None, fused=False, variant
 class _MaskEinsum(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, emb, pix):
+    def forward(ctx, emb, pix, tag=None):
         emb, pix = _req(emb, "emb"), _req(pix, "pix")
         B, Q, C = emb.shape
         if pix.dim() != 4 or pix.shape[0] != B or pix.shape[1] != C:
@@ -201,7 +201,7 @@ class _MaskEinsum(torch.autograd.Function):
         Hh, Ww = pix.shape[2:]
         out = torch.empty(B, Q, Hh, Ww, device=emb.device, dtype=emb.dtype)
         with torch.cuda.device(emb.device):
-            check(_timed("mask_einsum_fwd", emb, lambda: load().wm2f_mask_einsum_fwd(
+            check(_timed("mask_einsum_fwd" + (f"_{tag}" if tag else ""), emb, lambda: load().wm2f_mask_einsum_fwd(
                 _p(emb), _p(pix), _p(out), B, Q, C, Hh * Ww, WM2F_F32, _stream(emb))), "wm2f_mask_einsum_fwd")
         ctx.save_for_backward(emb, pix)
         return out
@@ -215,12 +215,12 @@ class _MaskEinsum(torch.autograd.Function):
         go = grad_out.reshape(B, Q, -1)
         g_emb = torch.bmm(go, pix.reshape(B, C, -1).transpose(1, 2)) if ctx.needs_input_grad[0] else None
         g_pix = torch.bmm(emb.transpose(1, 2), go).view_as(pix) if ctx.needs_input_grad[1] else None
-        return g_emb, g_pix
+        return g_emb, g_pix, None
 
 
-def mask_einsum(emb: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
-    """K3 -- einsum('bqc,bchw->bqhw') (HF:2046) on the fp32 matrix cores."""
-    return _MaskEinsum.apply(emb, pix)
+def mask_einsum(emb: torch.Tensor, pix: torch.Tensor, tag: str | None = None) -> torch.Tensor:
+    """K3 -- einsum('bqc,bchw->bqhw') (HF:2046) on the fp32 matrix cores.  `tag` only names the launch for the kernel timer."""
+    return _MaskEinsum.apply(emb, pix, tag)
 
 
 def nchw_to_pixel_major_bf16(pix: torch.Tensor) -> torch.Tensor:
@@ -509,6 +509,19 @@ def group_norm_tokens_(x: torch.Tensor, bias: torch.Tensor | None, groups: int, 
         check(load().wm2f_group_norm_tokens(_p(x), _p(bias), _p(gamma), _p(beta), _p(tokens), _p(ws), B, C, int(groups), H * W,
                                             int(tokens.shape[1]), int(start), float(eps), _stream(x)), "wm2f_group_norm_tokens")
     return tokens
+
+
+def resize_bilinear(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode="bilinear", align_corners=False) for an NCHW fp32 map (inference, no autograd)."""
+    if not x.is_contiguous():
+        raise ValueError("resize_bilinear: x must be NCHW-contiguous")
+    _req(x, "x")
+    N, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(load().wm2f_resize_bilinear(_p(x), _p(y), N * C, H, W, Ho, Wo, _stream(x)), "wm2f_resize_bilinear")
+    return y
 
 
 def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
