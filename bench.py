@@ -164,6 +164,10 @@ def main():
                                    f"bs={B} per GPU", "global_batch": world * B, "image_size": S,
                        "parallelism": f"dp{world}", "mode": a.mode},
         }
+        # which route built the attention masks: named by the launches that actually ran
+        line["config"]["attention_masks"] = ("einsum at level resolution for the 9 intermediate predictions, full resolution "
+                                             "for the returned one" if any(k.startswith("mask_einsum_fwd_hw") for k in ksum)
+                                             else "every prediction at full resolution")
         # ---- roofline of the dominant hand-written kernel (K1) and of K3
         L, P, H, D, Q = 3, 4, 8, 32, 100
         Stok = sum((S // s) ** 2 for s in (32, 16, 8))
