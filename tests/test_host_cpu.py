@@ -93,6 +93,24 @@ def test_product_refuses_cpu_tensors():
         m(pixel_values=torch.from_numpy(g["pixel_values"]))
 
 
+def test_fused_pass_ops_refuse_cpu_tensors():
+    """The fused inference passes have no CPU form either: each raises on host tensors instead of computing."""
+    from weed_instance_segmentation_amd import ops
+    from weed_instance_segmentation_amd._lib import Wm2fError
+    x, b = torch.randn(1, 8, 8, 8), torch.randn(8)
+    calls = [
+        lambda: ops.bias_act_(x.clone(), b),
+        lambda: ops.group_norm_act_(x.clone(), 2, b, b, 1e-5, up=torch.randn(1, 8, 4, 4)),
+        lambda: ops.group_norm_tokens_(x, b, 2, b, b, 1e-5, torch.zeros(1, 64, 8), 0),
+        lambda: ops.bias_relu_maxpool(x, b),
+        lambda: ops.resize_bilinear(x, (4, 4)),
+        lambda: ops.tokens_to_nchw(torch.randn(1, 64, 8), 0, 8, 8),
+    ]
+    for call in calls:
+        with pytest.raises(Wm2fError):
+            call()
+
+
 def test_collate_fn_batch_contract():
     """The batch dict the boundary consumes (datasets/dataset_utils.py:32-53), restated."""
     items = [dict(pixel_values=torch.zeros(3, 8, 8), mask_labels=torch.zeros(i + 1, 8, 8), class_labels=torch.zeros(i + 1, dtype=torch.int64))
