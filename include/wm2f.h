@@ -12,7 +12,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory unless marked "host";
  *     tensors are contiguous, row-major, in the shape written next to them;
- *   - nothing is allocated, freed or retained; there is no global mutable state;
+ *   - nothing is allocated, freed or retained; there is no global mutable state (host or device) and no
+ *     environment variable is read: behaviour is a function of the arguments alone;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no hidden syncs;
  *   - return 0 on success, a negative WM2F_E* code otherwise; wm2f_last_error() gives the
  *     thread-local message of the last failing call on this thread;
@@ -79,25 +80,21 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
                                    const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L,
                                    int P, int dtype, int margin, void* stream);
 
-/* Same two operations with the kernel variant exposed (A/B measurement, tuning):
+/* Same two operations with the kernel variant exposed (A/B measurement of kernels whose OUTPUTS ARE ALL VALID):
  *   fused   0: a = loc, b = attn_w, ref unused      1: a = offsets, b = logits, ref as above
- *   variant 0: auto   1: direct gather (any D)   2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4)
- *           12 / 22 / 32 / 42 / 52: timing ablations of the LDS-window kernel (staging only, gather
- *           only, no operand loads, no LDS reads, neither) -- their OUTPUTS ARE NOT VALID;
- *           62: LDS-window kernel with slab-major work order
+ *   variant 0: auto (tries 4, 3, 2, 1 in that order)
+ *           1: direct gather (any D)
+ *           2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4);  62: the same in slab-major work order
+ *           3: phased quad kernel (3 levels with sides 1:2:4 coarse first, P = 4, D = 32, margin 4)
+ *           4: streaming quad kernel (same shapes; persistent workgroups + loader waves)
+ *           5: streaming quad kernel with per-window flags instead of workgroup barriers
  *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that
  *           from their reference point take a slow path (results never depend on it).
- *           3 = phased quad kernel only (3 levels with sides 1:2:4 coarse first, P = 4, D = 32, margin 4);
- *           13 / 23 / 43 / 73 = its timing ablations / stamped build.  Variant 0 tries 3, then 2, then 1.
- * wm2f_msdeform_fwd / _fused_fwd are variant 0, margin 4. */
+ * Any other variant returns WM2F_EUNSUPPORTED: timing ablations and stamped builds live in the separate profiling
+ * library (include/wm2f_prof.h), never in libwm2f.so.  wm2f_msdeform_fwd / _fused_fwd are variant 0, margin 4. */
 int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const void* ref, void* out,
                         const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
                         int dtype, int fused, int variant, int margin, void* stream);
-
-/* Profiling aid for K1: variant 73 of wm2f_msdeform_fwd_v is the phased quad kernel with in-kernel time stamps
- * (s_memtime of wave 0, 16 slots per workgroup, first 8192 workgroups); this copies them to HOST memory
- * (int64 [8192][16], n_bytes <= 1 MiB).  Synchronous; no reference counterpart. */
-int wm2f_debug_stamps(void* host_dst, int64_t n_bytes);
 
 /* ---- K3 in bf16 (BASELINE configs 3-5: bf16 autocast) ---------------------------------------------
  * Same line as wm2f_mask_einsum_fwd (HF:2046) with bf16 operands, fp32 accumulation on the bf16 matrix cores and

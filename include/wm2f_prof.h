@@ -1,0 +1,32 @@
+/*
+ * wm2f_prof.h -- additions of the PROFILING build of the library (libwm2f_prof.so = the same sources compiled with
+ * -DWM2F_PROFILING; `python -m weed_instance_segmentation_amd._build --prof`).  Used by tools/ only: never by the
+ * product path, the tests' parity checks or bench.py.  It exports everything include/wm2f.h declares, plus:
+ *
+ *   - wm2f_msdeform_fwd_v accepts the timing ablations of K1, whose OUTPUTS ARE NOT VALID:
+ *       12 / 22 / 32 / 42 / 52  LDS-window kernel: staging only, gather only, no operand loads, no LDS reads, neither
+ *       13 / 23 / 43            phased quad kernel: staging only, gather only, no LDS reads
+ *       44                      streaming quad kernel without LDS reads
+ *       73 / 74                 phased / streaming quad kernel with in-kernel time stamps (valid outputs)
+ *   - K2 / K3 read their experiment knobs from the environment on every launch
+ *       WM2F_K2_QTILES, WM2F_K2_WG_TARGET, WM2F_K2_FULL, WM2F_K2_QSPLIT, WM2F_K3_DBG   (tools/kbench.py)
+ *   - the stamp buffer below: a __device__ global, i.e. the global mutable state the production library forbids.
+ */
+#ifndef WM2F_PROF_H
+#define WM2F_PROF_H
+
+#include "wm2f.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Variants 73 / 74 of wm2f_msdeform_fwd_v stamp s_memtime of one gather wave and one loader wave (16 slots per
+ * workgroup, first 8192 workgroups); this copies the stamps to HOST memory (int64 [8192][16], n_bytes <= 1 MiB).
+ * Synchronous; no reference counterpart. */
+int wm2f_debug_stamps(void* host_dst, int64_t n_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM2F_PROF_H */

@@ -54,6 +54,51 @@ def test_sample_files_round_trip_and_collate_contract(tmp_path):
     assert size_c < size_full / 2  # toy sizes: pixel_values dominate; at 1024 x 1024 with 16 instances it is 64 MB vs 4 MB
 
 
+def test_reference_written_samples_load_and_collate_like_the_reference():
+    """tests/golden/ref_samples/*.pt were written by the REFERENCE's process_and_save (datasets/dataset_utils.py:56-70)
+    from items shaped like PhenoBenchDataset.__getitem__'s (datasets/pheno_bench/dataset.py:127-135: numpy int32
+    `original_map`, int-keyed `id_to_semantic`, tuple `target_size`); ref_samples_batch.npz is what the reference's own
+    PreprocessedDataset + collate_fn (:7-53) made of them (tests/golden/make_reference_samples.py).  This module's loader
+    -- which executes nothing from the files -- must give the same batch, type for type."""
+    from weed_instance_segmentation_amd import data
+    g = load_golden("ref_samples_batch.npz")
+    meta = json.loads(str(g["meta_json"]))
+    ds = data.PreprocessedDataset(os.path.join(os.path.dirname(__file__), "golden", "ref_samples"))
+    assert [os.path.basename(f) for f in ds.files] == meta["files"] and len(ds) == int(g["n"]) == 3
+    b = data.collate_fn([ds[i] for i in range(len(ds))])
+    assert set(b) == {"pixel_values", "mask_labels", "class_labels", "target_sizes", "original_maps", "id_mappings", "file_names"}
+    assert torch.equal(b["pixel_values"], T(g["pixel_values"])) and b["file_names"] == meta["file_names"]
+    for i in range(3):
+        assert torch.equal(b["mask_labels"][i], T(g[f"mask_labels_{i}"])) and b["mask_labels"][i].dtype == torch.float32
+        assert torch.equal(b["class_labels"][i], T(g[f"class_labels_{i}"])) and b["class_labels"][i].dtype == torch.int64
+        assert isinstance(b["original_maps"][i], np.ndarray) and b["original_maps"][i].dtype == np.int32
+        assert np.array_equal(b["original_maps"][i], g[f"original_map_{i}"])
+        assert isinstance(b["target_sizes"][i], tuple) and list(b["target_sizes"][i]) == meta["target_sizes"][i]
+        assert b["id_mappings"][i] == {int(k): v for k, v in meta["id_mappings"][i].items()}
+        assert all(isinstance(k, int) for k in b["id_mappings"][i])
+    assert b["mask_labels"][2].shape[0] == 0  # an image without instances keeps an empty (0, H, W) stack
+    # what models/metrics.py:27-52 does with a batch: numpy ops on original_maps, `uid in mapping` with int keys
+    uids = [int(u) for u in np.unique(b["original_maps"][1]) if u != 255 and u in b["id_mappings"][1]]
+    assert uids == sorted(b["id_mappings"][1])
+
+
+def test_sample_loader_refuses_everything_but_plain_arrays(tmp_path):
+    """The allow-list admits numeric numpy arrays only: a pickle that names any other global (here os.system), or an
+    object array, is refused -- nothing from a sample file is ever executed."""
+    import pickle
+    from weed_instance_segmentation_amd import data
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    torch.save({"x": Evil()}, str(tmp_path / "evil.pt"))
+    torch.save({"x": np.array([{"a": 1}], dtype=object)}, str(tmp_path / "obj.pt"))
+    for name in ("evil.pt", "obj.pt"):
+        with pytest.raises(pickle.UnpicklingError):
+            data.load_sample(str(tmp_path / name))
+
+
 @pytest.mark.gpu
 def test_expand_labels_on_device_matches_dependency(tmp_path):
     if not torch.cuda.is_available():

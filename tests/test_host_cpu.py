@@ -33,6 +33,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.wm2f_version() == 100  # host-only call, no GPU needed
 
 
+def test_production_library_has_no_profiling_surface():
+    """include/wm2f.h promises: no global mutable state, no environment reads, valid outputs only.  The stamp buffer,
+    wm2f_debug_stamps, the K1 timing ablations and the getenv knobs of K2 / K3 live in libwm2f_prof.so
+    (include/wm2f_prof.h, -DWM2F_PROFILING), which only tools/ load."""
+    import subprocess
+    from weed_instance_segmentation_amd import _build, _lib
+    lib = ctypes.CDLL(_build.build())
+    for name in _lib.PROF_SIGNATURES:
+        assert not hasattr(lib, name), f"production library exports {name}"
+    nm = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert " getenv" not in nm and "g_stamps" not in nm, "production library reads the environment / holds the stamp buffer"
+    prof_h = open(os.path.join(ROOT, "include", "wm2f_prof.h")).read()
+    declared = set(re.findall(r"\b(wm2f_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", prof_h, flags=re.S)))
+    assert declared == set(_lib.PROF_SIGNATURES)
+    prof = ctypes.CDLL(_build.build(prof=True))
+    for name in list(_lib.SIGNATURES) + list(_lib.PROF_SIGNATURES):
+        assert hasattr(prof, name), name
+    # nothing the product, the tests' parity checks or bench.py import ever switches libraries
+    for path in [os.path.join(PKG, f) for f in os.listdir(PKG) if f.endswith(".py") and f != "_lib.py"] + [os.path.join(ROOT, "bench.py")]:
+        assert "use_profiling_library" not in open(path).read(), path
+
+
 def test_state_dict_names_match_dependency():
     from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
     ks = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
@@ -109,15 +131,6 @@ def test_fused_pass_ops_refuse_cpu_tensors():
     for call in calls:
         with pytest.raises(Wm2fError):
             call()
-
-
-def test_collate_fn_batch_contract():
-    """The batch dict the boundary consumes (datasets/dataset_utils.py:32-53), restated."""
-    items = [dict(pixel_values=torch.zeros(3, 8, 8), mask_labels=torch.zeros(i + 1, 8, 8), class_labels=torch.zeros(i + 1, dtype=torch.int64))
-             for i in range(2)]
-    batch = dict(pixel_values=torch.stack([it["pixel_values"] for it in items]),
-                 mask_labels=[it["mask_labels"] for it in items], class_labels=[it["class_labels"] for it in items])
-    assert batch["pixel_values"].shape == (2, 3, 8, 8) and isinstance(batch["mask_labels"], list)
 
 
 def test_swin_backbone_matches_golden_and_names():

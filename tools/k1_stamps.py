@@ -6,8 +6,9 @@ import argparse, ctypes, json, os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from weed_instance_segmentation_amd import ops
+from weed_instance_segmentation_amd import _lib, ops
 from weed_instance_segmentation_amd._lib import load, check
+_lib.use_profiling_library()  # stamped kernels exist only in libwm2f_prof.so (include/wm2f_prof.h)
 
 NAMES = ["setup+operand loads issue", "DMA issue", "wait coarse(+operands)", "softmax/coords", "barrier0", "phase0 gather",
          "wait mid", "barrier1", "phase1 gather", "wait fine", "barrier2", "phase2 gather", "slow+stores"]

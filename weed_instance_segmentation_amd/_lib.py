@@ -10,9 +10,12 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwm2f.so")
+PROF_LIB_PATH = os.path.join(HERE, "libwm2f_prof.so")  # profiling build (include/wm2f_prof.h): tools/ only
 
 WM2F_F32 = 0
 WM2F_BF16 = 1
+# return codes of include/wm2f.h
+WM2F_OK, WM2F_EINVAL, WM2F_EUNSUPPORTED, WM2F_ELAUNCH = 0, -1, -2, -3
 
 _P = c_void_p
 _I = c_int
@@ -27,7 +30,6 @@ SIGNATURES = {
     "wm2f_msdeform_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "wm2f_debug_stamps": (c_int, [_P, c_int64]),
     "wm2f_point_sample_levels_fwd": (c_int, [POINTER(c_void_p), _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_levels_bwd": (c_int, [_P, _P, _P, POINTER(c_void_p), _I, _I, _I, _I, _I, _P]),
     "wm2f_mask_loss_rows_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P]),
@@ -61,11 +63,31 @@ SIGNATURES = {
     "wm2f_point_sample_bwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
 }
 
+# additions of the profiling library (include/wm2f_prof.h)
+PROF_SIGNATURES = {"wm2f_debug_stamps": (c_int, [_P, c_int64])}
+
 _lib = None
 
 
 class Wm2fError(RuntimeError):
     pass
+
+
+def use_profiling_library() -> ctypes.CDLL:
+    """tools/ only: make `load()` return libwm2f_prof.so (timing ablations, stamped kernels, environment knobs).  Must be
+    called before the first `load()`; raises when that library has not been built
+    (`python -m weed_instance_segmentation_amd._build --prof`)."""
+    global _lib
+    if _lib is not None:
+        raise Wm2fError("use_profiling_library() must come before the first kernel call")
+    if not os.path.exists(PROF_LIB_PATH):
+        raise Wm2fError(f"{PROF_LIB_PATH} not found: python -m weed_instance_segmentation_amd._build --prof")
+    lib = ctypes.CDLL(PROF_LIB_PATH)
+    for name, (res, args) in {**SIGNATURES, **PROF_SIGNATURES}.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
 
 
 def load() -> ctypes.CDLL:

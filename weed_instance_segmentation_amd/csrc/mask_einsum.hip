@@ -210,8 +210,12 @@ extern "C" int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out,
   // History: with the row offset in the stores' SGPR offset (see the epilogue) padded rows were written out of bounds
   // and, at C = 64, launches of this remainder variant lost a few lanes of one main-tile store; both are gone with
   // the row in the vector offset (tools/probes/k3_grid_probe.py, k3_rem_probe.py, k3_rem_stress.py: clean).
+#ifdef WM2F_PROFILING
   const char* e_dbg = getenv("WM2F_K3_DBG");
-  const int dbg = e_dbg ? atoi(e_dbg) : 0;  // probe knob: 1 skips the remainder FMAs, 2 the remainder epilogue
+  const int dbg = e_dbg ? atoi(e_dbg) : 0;  // probe knob (profiling build only): 1 skips the remainder FMAs, 2 the remainder epilogue
+#else
+  const int dbg = 0;
+#endif
   if (left > 0 && left <= 4 && MT >= 1 && MT <= 6 && Q == q_chunks * rows_per_chunk && true) REM = 4;  // exact split only
   else if (left > 0) MT += 1;
   if (MT > mt_cap) {  // fall back to plain padding with one more chunk

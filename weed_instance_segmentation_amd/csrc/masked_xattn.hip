@@ -30,10 +30,16 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kXWaves = 4;
 
-static inline int tune_env(const char* name, int dflt) {  // experiment knobs (tools/kbench.py); unset in production
+// Experiment knobs of tools/kbench.py (WM2F_K2_*): environment variables in the PROFILING build (libwm2f_prof.so,
+// -DWM2F_PROFILING) only; the production library is compiled with the defaults and reads no environment.
+#ifdef WM2F_PROFILING
+static inline int tune_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
 }
+#else
+static inline constexpr int tune_env(const char*, int dflt) { return dflt; }
+#endif
 
 // Key splits.  Forward: measured at config 2 (tools/kbench.py --only k2, knobs WM2F_K2_QTILES / WM2F_K2_WG_TARGET):
 // 2 query tiles per workgroup (4 query chunks, ~150 registers -> 3 waves per SIMD instead of 1 at 7 tiles) and 512

@@ -290,6 +290,15 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   WM2F_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64, "%s: head_dim %d not in {8,16,32,64}", who, D);
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+#ifndef WM2F_PROFILING
+  // the production library launches only kernels whose outputs are valid: 0 auto, 1 direct gather, 2 LDS windows,
+  // 3 phased quads, 4 streaming quads, 5 streaming with flags, 62 LDS windows in slab-major order
+  if (!(variant >= 0 && variant <= 5) && variant != 62) {
+    set_error("%s: variant %d is a timing ablation / stamped build: profiling library only (libwm2f_prof.so, "
+              "include/wm2f_prof.h)", who, variant);
+    return WM2F_EUNSUPPORTED;
+  }
+#endif
   if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || variant == 5)) {
     bool handled = false;
     if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,

@@ -50,12 +50,19 @@ struct QuadGeom {
 
 // MODE 7 (variant 73): the kernel with in-kernel time stamps (s_memtime, wave 0 of each workgroup),
 // read back with wm2f_debug_stamps.  A profiling aid; no other mode touches this buffer.
+// The stamp buffer -- the library's only device global -- and every ablation / stamped instantiation exist in the
+// PROFILING build alone (libwm2f_prof.so, -DWM2F_PROFILING, include/wm2f_prof.h); the production library carries
+// MODE 0 kernels only and no global mutable state.
 constexpr int kStampSlots = 16, kStampGroups = 8192;
+#ifdef WM2F_PROFILING
 __device__ long long g_stamps[kStampGroups * kStampSlots];
 #define WM2F_STAMP(k)                                                                  \
   do {                                                                                 \
     if (MODE == 7 && tid == 0 && id < kStampGroups) g_stamps[id * kStampSlots + (k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+#else
+#define WM2F_STAMP(k) do { } while (0)
+#endif
 
 template <int K>
 __device__ __forceinline__ float bcast(float v) {  // value of lane K of this lane's quad
@@ -551,11 +558,15 @@ static_assert(LWin<0>::n == 13 && LWin<1>::n == 21 && LWin<2>::n == 43, "vmcnt c
 
 // MODE 7 stamps of the streaming kernel: the workgroup's SECOND tile (steady state); slots 0-9 by wave 0 (gather),
 // 10-15 by wave 8 (loader).
+#ifdef WM2F_PROFILING
 #define WM2F_SSTAMP(slot, who)                                                                              \
   do {                                                                                                      \
     if (MODE == 7 && k == 1 && tid == (who) * 64 && blockIdx.x < kStampGroups)                              \
       g_stamps[blockIdx.x * kStampSlots + (slot)] = (long long)__builtin_readcyclecounter();                \
   } while (0)
+#else
+#define WM2F_SSTAMP(slot, who) do { } while (0)
+#endif
 
 struct StreamGeom {
   QuadGeom q;
@@ -1048,10 +1059,12 @@ int launch_quad(const void* value, const void* a, const void* b, void* out, cons
     return WM2F_OK;
   const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
   auto kfn = msdeform_quad_fwd_kernel<FUSED, 0>;
+#ifdef WM2F_PROFILING
   if (mode == 1) kfn = msdeform_quad_fwd_kernel<FUSED, 1>;
   if (mode == 2) kfn = msdeform_quad_fwd_kernel<FUSED, 2>;
   if (mode == 4) kfn = msdeform_quad_fwd_kernel<FUSED, 4>;
   if (mode == 7) kfn = msdeform_quad_fwd_kernel<FUSED, 7>;
+#endif
   hipLaunchKernelGGL(kfn, dim3(per_xcd * kNumXcd), dim3(kThreads), 0, (hipStream_t)stream, (const float*)value,
                      (const float*)a, (const float*)b, (float*)out, g, S, Q, heads, (int)n_logical, per_xcd);
   hipError_t e = hipGetLastError();
@@ -1118,8 +1131,10 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_ntiles = 1.f / (float)(g.tiles_x * g.tiles_y);
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
   auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0>;
+#ifdef WM2F_PROFILING
   if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0>;
   if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0>;
+#endif
   if (mode == 100) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1>;  // flags instead of barriers
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(kSThreads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
@@ -1139,7 +1154,8 @@ template int launch_stream<true>(const void*, const void*, const void*, void*, c
 
 }  // namespace wm2f
 
-// Copy the MODE-7 time stamps (int64 [8192 workgroups][16 slots], s_memtime ticks) to host memory.
+#ifdef WM2F_PROFILING
+// Copy the MODE-7 time stamps (int64 [8192 workgroups][16 slots], s_memtime ticks) to host memory (include/wm2f_prof.h).
 extern "C" int wm2f_debug_stamps(void* host_dst, int64_t n_bytes) {
   using namespace wm2f;
   WM2F_REQUIRE(host_dst && n_bytes > 0 && n_bytes <= (int64_t)sizeof(long long) * kStampGroups * kStampSlots,
@@ -1151,3 +1167,4 @@ extern "C" int wm2f_debug_stamps(void* host_dst, int64_t n_bytes) {
   }
   return WM2F_OK;
 }
+#endif  // WM2F_PROFILING

@@ -322,14 +322,20 @@ int launch_tiled(const void* value, const void* a, const void* b, void* out, con
   if (n_logical > (1 << 30)) return WM2F_OK;
   const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
   hipStream_t st = (hipStream_t)stream;
+#ifdef WM2F_PROFILING  /* timing ablations (invalid outputs): profiling build only */
+#define WM2F_TL_ABLATIONS(NLv)                                                          \
+    if (NLv == 3 && mode == 1) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 1>;    \
+    if (NLv == 3 && mode == 2) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 2>;    \
+    if (NLv == 3 && mode == 3) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 3>;    \
+    if (NLv == 3 && mode == 4) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 4>;    \
+    if (NLv == 3 && mode == 5) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 5>;
+#else
+#define WM2F_TL_ABLATIONS(NLv)
+#endif
 #define WM2F_TL(NLv)                                                                                              \
   case NLv: {                                                                                                     \
     auto kfn = msdeform_tiled_fwd_kernel<NLv, 4, FUSED, 512>;                                                     \
-    if (NLv == 3 && mode == 1) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 1>;                              \
-    if (NLv == 3 && mode == 2) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 2>;                              \
-    if (NLv == 3 && mode == 3) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 3>;                              \
-    if (NLv == 3 && mode == 4) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 4>;                              \
-    if (NLv == 3 && mode == 5) kfn = msdeform_tiled_fwd_kernel<3, 4, FUSED, 512, 5>;                              \
+    WM2F_TL_ABLATIONS(NLv)                                                                                        \
     if (p.lds_bytes > 64 * 1024) {                                                                                \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,           \
                                          (int)p.lds_bytes);                                                       \
@@ -346,6 +352,7 @@ int launch_tiled(const void* value, const void* a, const void* b, void* out, con
     default: return WM2F_OK;
   }
 #undef WM2F_TL
+#undef WM2F_TL_ABLATIONS
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: tiled launch failed: %s", who, hipGetErrorString(e));

@@ -10,21 +10,50 @@ This module keeps the reference's file layout, key names and `collate_fn` contra
 (H, W) instance-id map plus the id -> class dictionary (`instance_map`, `id_to_semantic`; both already in the
 reference's dictionary under `original_map` / `id_to_semantic` semantics) instead of the mask stack.  The stack is
 then produced on the device by `expand_labels` (HIP: `wm2f_labelmap_to_masks`) as uint8, which the loss and the
-matcher read directly.  Full samples written by the reference keep loading.
+matcher read directly.  Full samples written by the reference keep loading: `tests/golden/ref_samples/*.pt` were written
+by the reference's own `process_and_save` (`tests/golden/make_reference_samples.py`) and `tests/test_data.py` holds this
+module to what the reference's own loader and `collate_fn` make of them.
 
-Files are read with `torch.load(..., weights_only=True)` (tensors, numbers, strings, tuples, dicts only).
+Files are read with `torch.load(..., weights_only=True)`: nothing in a file is executed.  The reference's samples carry
+`original_map` as a NUMPY array (`datasets/pheno_bench/dataset.py:85`, `:132`), which the restricted unpickler refuses
+by default; exactly the three globals a plain numeric array pickles to (`numpy.ndarray`, `numpy.dtype`, numpy's
+`_reconstruct`) plus numpy's numeric dtype classes are allow-listed for the duration of the load.  Object arrays stay
+refused (they would need arbitrary globals), and so does everything else a pickle can name.
 """
 from __future__ import annotations
 
 import glob
 import os
 
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
 from . import ops
 
 IGNORE_INDEX = 255  # the reference's choice: datasets/pheno_bench/dataset.py:85, :121
+
+
+def _numpy_array_globals() -> list:
+    """What a numeric numpy array inside a pickled sample names: the array type, the dtype type, the reconstruct helper
+    (numpy 1.x pickles call it numpy.core.multiarray._reconstruct, numpy 2.x numpy._core.multiarray._reconstruct: the
+    installed numpy resolves both to the same function) and, from numpy 1.25 on, the per-dtype classes."""
+    try:
+        from numpy._core.multiarray import _reconstruct  # numpy >= 2
+    except ImportError:  # pragma: no cover
+        from numpy.core.multiarray import _reconstruct
+    allowed = [np.ndarray, np.dtype, _reconstruct, (_reconstruct, "numpy.core.multiarray._reconstruct"),
+               (_reconstruct, "numpy._core.multiarray._reconstruct")]
+    for name in ("bool_", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float16", "float32",
+                 "float64"):
+        allowed.append(type(np.dtype(getattr(np, name))))
+    return allowed
+
+
+def load_sample(path: str) -> dict:
+    """One sample dictionary from a `.pt` file, executing nothing from the file (see the module docstring)."""
+    with torch.serialization.safe_globals(_numpy_array_globals()):
+        return torch.load(path, weights_only=True)
 
 
 class PreprocessedDataset(Dataset):
@@ -41,7 +70,7 @@ class PreprocessedDataset(Dataset):
         return len(self.files)
 
     def __getitem__(self, idx):
-        return torch.load(self.files[idx], weights_only=True)
+        return load_sample(self.files[idx])
 
 
 def collate_fn(batch) -> dict:

@@ -163,7 +163,7 @@ def ms_deform_attn_fused_packed(value, level_hw, packed, ref, heads: int, L: int
     with torch.cuda.device(value.device):
         rc = _timed("msdeform_fused_fwd", value, lambda: load().wm2f_msdeform_fused_packed_fwd(
             _p(value), _p(packed), _p(out), lv, B, S, Q, H, D, L, P, WM2F_F32, int(margin), _stream(value)))
-    if rc == -2:  # WM2F_EUNSUPPORTED: shape outside the LDS-window kernel -> direct-gather HIP kernel
+    if rc == _lib.WM2F_EUNSUPPORTED:  # shape outside the LDS-window kernels -> direct-gather HIP kernel
         n_off = heads * L * P * 2
         off = packed[..., :n_off].reshape(B, Q, heads, L, P, 2).contiguous()
         logits = packed[..., n_off:].reshape(B, Q, heads, L * P).contiguous()
