@@ -153,16 +153,23 @@ def main():
     if rank == 0:
         ksum = timer.summary()
         value = world * B * a.steps / dt
+        prec = "fp32" if a.amp == "off" else "bf16 autocast"
+        what = "forward-only" if a.mode == "fwd" else "full train step (Hungarian matching + mask/dice/class loss + backward + AdamW)"
+        # which BASELINE.json configuration this run is (the default flags are configs[1], the headline metric)
+        if (a.mode, a.amp, B, S) == ("fwd", "off", 8, 1024):
+            which = "BASELINE.json configs[1]"
+        elif (a.mode, a.amp, B, S) == ("train", "bf16", 16, 1024):
+            which = "BASELINE.json configs[2]"
+        else:
+            which = "variant of BASELINE.json configs[1] (not a BASELINE configuration)"
         line = {
-            "metric": "images/sec at 1024x1024 bs=8 per GPU (Mask2Former R50, 100 queries, "
-                      + ("fp32" if a.amp == "off" else "bf16-autocast") + (" forward-only)" if a.mode == "fwd" else " full train step)"),
+            "metric": f"images/sec at {S}x{S} bs={B} per GPU (Mask2Former R50, 100 queries, {prec} {what.split(' (')[0]})",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.amp == "off" else "bf16 autocast (stock ops bf16, wm2f kernels f32)", "data": "synthetic (randn pixels, random-init weights seed 0)",
-            "config": {"workload": f"BASELINE.json configs[1]: synthetic {S}x{S} 3-class, ResNet-50 Mask2Former, "
-                                   f"100 queries, {'fp32' if a.amp == 'off' else 'bf16 autocast'} {'forward-only' if a.mode == 'fwd' else 'train step'}, "
+            "config": {"workload": f"{which}: synthetic {S}x{S} 3-class, ResNet-50 Mask2Former, 100 queries, {prec} {what}, "
                                    f"bs={B} per GPU", "global_batch": world * B, "image_size": S,
-                       "parallelism": f"dp{world}", "mode": a.mode},
+                       "parallelism": f"dp{world}", "mode": a.mode, "amp": a.amp},
         }
         # which route built the attention masks: named by the launches that actually ran
         line["config"]["attention_masks"] = ("einsum at level resolution for the 9 intermediate predictions, full resolution "

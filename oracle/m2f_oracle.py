@@ -213,7 +213,7 @@ def hungarian(cost):
 # ----------------------------------------------------------------------------- loss (a7)
 def num_labels(cfg):
     """config.json stores id2label, not num_labels."""
-    return int(num_labels(cfg)) if "num_labels" in cfg else len(cfg["id2label"])
+    return int(cfg["num_labels"]) if cfg.get("num_labels") is not None else len(cfg["id2label"])
 
 
 class RandSource:
@@ -396,8 +396,14 @@ def _self_attention(sd, p, h, qpos, nh):
     return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"]).permute(1, 0, 2)
 
 
-def transformer_module(sd, prefix, multi_scale, mask_features, cfg):
-    """HF:2059-2129 + HF:1801-1960 (post-norm layers, eval: no layer drop)."""
+def transformer_module(sd, prefix, multi_scale, mask_features, cfg, forced_masks=None, record=None):
+    """HF:2059-2129 + HF:1801-1960 (post-norm layers, eval: no layer drop).
+
+    Checker options (no counterpart in the dependency): `forced_masks` = one (B, Q, HW_l) bool/uint8 mask per decoder
+    layer, used INSTEAD of the bits thresholded here -- with random weights some resized logits sit within rounding of
+    the 0.5 threshold, and a single flipped bit changes that query from there on; feeding both sides the same bits
+    makes every later comparison exact, while `record` (a list) receives, per layer, the resized logits whose sign
+    decides the oracle's own bits, so the bits themselves can be compared wherever they are not ambiguous."""
     hd, nh = cfg["hidden_dim"], cfg["num_attention_heads"]
     B = mask_features.shape[0]
     feats, poss, sizes = [], [], []
@@ -411,8 +417,17 @@ def transformer_module(sd, prefix, multi_scale, mask_features, cfg):
     h = sd[prefix + "queries_features.weight"].unsqueeze(1).repeat(1, B, 1)
     dp = prefix + "decoder."
     ln = lambda t: F.layer_norm(t, (hd,), sd[dp + "layernorm.weight"], sd[dp + "layernorm.bias"])
+
+    def predict(state, size, layer):
+        logits, amask = mask_predictor(sd, dp + "mask_predictor.", state, mask_features, size)
+        if record is not None:
+            record.append(F.interpolate(logits, size=tuple(int(x) for x in size), mode="bilinear", align_corners=False).flatten(2))
+        if forced_masks is not None and layer < len(forced_masks):
+            amask = torch.as_tensor(forced_masks[layer]).to(torch.bool).reshape(amask.shape)
+        return logits, amask
+
     inter = [ln(h)]
-    logits, amask = mask_predictor(sd, dp + "mask_predictor.", inter[0], mask_features, sizes[0])
+    logits, amask = predict(inter[0], sizes[0], 0)
     all_masks = [logits]
     for idx in range(cfg["decoder_layers"] - 1):
         lvl = idx % 3
@@ -424,18 +439,18 @@ def transformer_module(sd, prefix, multi_scale, mask_features, cfg):
         f = F.linear(F.relu(F.linear(h, sd[lp + "fc1.weight"], sd[lp + "fc1.bias"])), sd[lp + "fc2.weight"], sd[lp + "fc2.bias"])
         h = F.layer_norm(h + f, (hd,), sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"])
         inter.append(ln(h))
-        logits, amask = mask_predictor(sd, dp + "mask_predictor.", inter[-1], mask_features, sizes[(idx + 1) % 3])
+        logits, amask = predict(inter[-1], sizes[(idx + 1) % 3], idx + 1)
         all_masks.append(logits)
     return inter, all_masks
 
 
 def forward(sd, cfg, pixel_values, mask_labels=None, class_labels=None, rand_source=None, backbone_feats=None,
-            grad=False):
+            grad=False, forced_masks=None):
     """Mask2FormerForUniversalSegmentation.forward, HF:2332-2530, eval mode.
 
     sd: state dict with the dependency's names.  cfg: its config as a dict.
     Returns dict(masks_queries_logits, class_queries_logits, aux_masks, aux_classes, loss, loss_dict, indices,
-    mask_features, multi_scale, backbone)."""
+    mask_features, multi_scale, backbone, mask_decisions).  `forced_masks` / `mask_decisions`: see transformer_module."""
     sd = {k: v.float() if (v.is_floating_point() and v.dtype != torch.float32) else v for k, v in sd.items()}
     with torch.enable_grad() if grad else torch.no_grad():
         rs = rand_source or RandSource()
@@ -447,11 +462,13 @@ def forward(sd, cfg, pixel_values, mask_labels=None, class_labels=None, rand_sou
                 raise NotImplementedError("oracle backbone: resnet only")
             feats = resnet_backbone(sd, "model.pixel_level_module.encoder.", pixel_values, cfg)
         mask_features, multi_scale = pixel_decoder(sd, "model.pixel_level_module.decoder.", feats, cfg)
-        inter, all_masks = transformer_module(sd, "model.transformer_module.", multi_scale, mask_features, cfg)
+        decisions = []
+        inter, all_masks = transformer_module(sd, "model.transformer_module.", multi_scale, mask_features, cfg,
+                                              forced_masks=forced_masks, record=decisions)
         all_classes = [F.linear(s.transpose(0, 1), sd["class_predictor.weight"], sd["class_predictor.bias"]) for s in inter]
         res = dict(masks_queries_logits=all_masks[-1], class_queries_logits=all_classes[-1], aux_masks=all_masks[:-1],
                    aux_classes=all_classes[:-1], mask_features=mask_features, multi_scale=multi_scale, backbone=feats,
-                   loss=None, loss_dict=None, indices=None)
+                   loss=None, loss_dict=None, indices=None, mask_decisions=decisions)
         if mask_labels is not None and class_labels is not None:
             loss, ld, idx = criterion(all_masks, all_classes, mask_labels, class_labels, rs, cfg)
             res.update(loss=loss, loss_dict=ld, indices=idx)

@@ -434,6 +434,14 @@ def gen_state_keys():
         m = Mask2FormerForUniversalSegmentation(Mask2FormerConfig(backbone_config=sc, num_labels=3, num_queries=100))
         res["swin_tiny_q100_l3"] = {k: list(v.shape) for k, v in m.state_dict().items()}
         res["swin_tiny_config"] = json.loads(json.dumps(m.config.to_dict(), default=str))
+        # the checkpoint family the reference itself trains from (config.py:4 `facebook/mask2former-swin-large-coco-
+        # instance`): Swin-L (embed 192, depths 2-2-18-2, heads 6-12-24-48, window 12, 384 px pretraining), 200 queries,
+        # 80 COCO classes -- built from a LOCAL config on the meta device (no download, no weights)
+        sl = SwinConfig(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=12, image_size=384,
+                        drop_path_rate=0.3, out_features=["stage1", "stage2", "stage3", "stage4"])
+        m = Mask2FormerForUniversalSegmentation(Mask2FormerConfig(backbone_config=sl, num_labels=80, num_queries=200))
+        res["swin_large_q200_l80"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        res["swin_large_config"] = json.loads(json.dumps(m.config.to_dict(), default=str))
     res["hf_version"] = META["hf_version"]
     with open(os.path.join(HERE, "state_keys.json"), "w") as f:
         json.dump(res, f)

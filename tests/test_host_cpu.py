@@ -190,3 +190,64 @@ def test_legacy_swin_checkpoint_names_load(tmp_path):
     for k in a:
         if ".swin.layernorm." not in k:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_swin_large_200_query_checkpoint_family_names():
+    """The reference trains from `facebook/mask2former-swin-large-coco-instance` (config.py:4: Swin-L, window 12, 200
+    queries, 80 classes).  Same 760 tensor names and shapes as the dependency builds for that configuration (fixture from a
+    local config on the meta device: tests/golden/make_golden.py keys)."""
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    ks = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+    cfg = Mask2FormerConfig.from_dict(ks["swin_large_config"])
+    assert cfg.num_queries == 200 and cfg.backbone_config["window_size"] == 12 and cfg.num_labels == 80
+    with torch.device("meta"):
+        m = Mask2FormerForUniversalSegmentation(cfg)
+    own, exp = m.state_dict(), ks["swin_large_q200_l80"]
+    assert set(own) == set(exp) and len(exp) == 760
+    assert all(list(own[k].shape) == exp[k] for k in exp)
+
+
+def test_dependency_class_loads_a_directory_written_here(tmp_path):
+    """save_pretrained of this package -> the installed transformers class' from_pretrained(local_dir) (what
+    models/mask2former/train.py:245 and models/model_utils.py:14 call): every tensor arrives, bit for bit, and the
+    dependency's own forward runs on it.  Runs in the build container only (the dependency is imported by a TEST)."""
+    tr = pytest.importorskip("transformers")
+    from conftest import load_golden
+    from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    g = load_golden("full_tiny.npz")
+    cfg = Mask2FormerConfig.from_dict(json.loads(str(g["config_json"])))
+    m = Mask2FormerForUniversalSegmentation(cfg)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)
+    m.save_pretrained(str(tmp_path))
+    hf = tr.Mask2FormerForUniversalSegmentation.from_pretrained(str(tmp_path)).eval()
+    theirs = hf.state_dict()
+    assert set(theirs) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(theirs[k], v), k
+    assert {int(k): v for k, v in hf.config.id2label.items()} == cfg.id2label
+    with torch.no_grad():
+        out = hf(pixel_values=torch.from_numpy(g["pixel_values"]))
+    ref = torch.from_numpy(g["masks_queries_logits"])
+    assert (out.masks_queries_logits - ref).abs().max().item() / ref.abs().max().item() < 1e-5  # the golden, reproduced
+
+
+def test_dependency_processor_consumes_the_output_object():
+    """models/metrics.py:58-63 / inference.py:30 hand the model's output object to the dependency's
+    post_process_instance_segmentation, which reads `.class_queries_logits` / `.masks_queries_logits`
+    (image_processing_pil_mask2former.py:714-716): the output class of this package is accepted as is and gives the
+    fixture's result."""
+    pytest.importorskip("transformers")
+    from transformers.models.mask2former.image_processing_pil_mask2former import Mask2FormerImageProcessorPil
+    from conftest import load_golden
+    from weed_instance_segmentation_amd.modeling import Mask2FormerForUniversalSegmentationOutput
+    g = load_golden("postprocess_instances.npz")
+    info = json.loads(str(g["info_json"]))
+    out = Mask2FormerForUniversalSegmentationOutput(class_queries_logits=torch.from_numpy(g["class_logits"]),
+                                                    masks_queries_logits=torch.from_numpy(g["mask_logits"]))
+    ts = [tuple(t) for t in info["mixed"]["target_sizes"]]
+    res = Mask2FormerImageProcessorPil().post_process_instance_segmentation(out, threshold=0.5, mask_threshold=0.5, target_sizes=ts)
+    for i, r in enumerate(res):
+        assert torch.equal(r["segmentation"].to(torch.int16), torch.from_numpy(g[f"seg_mixed_{i}"]))
+        assert [s["label_id"] for s in r["segments_info"]] == [s["label_id"] for s in info["mixed"]["segments_info"][i]]

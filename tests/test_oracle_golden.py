@@ -92,3 +92,10 @@ def test_full_forward_and_loss():
     for k, v in res["loss_dict"].items():
         torch.testing.assert_close(v, T(g["ld." + k]), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(res["loss"], T(g["loss"]), rtol=1e-4, atol=1e-4)
+
+
+def test_num_labels_reads_either_config_form():
+    """config.json stores id2label; a config dict may also carry num_labels (it used to recurse forever)."""
+    assert O.num_labels({"id2label": {"0": "a", "1": "b", "2": "c"}}) == 3
+    assert O.num_labels({"num_labels": 5, "id2label": {"0": "a"}}) == 5
+    assert O.num_labels({"num_labels": None, "id2label": {"0": "a", "1": "b"}}) == 2

@@ -36,13 +36,13 @@ def _data(rank, step):
     return torch.randn(5, 8, generator=g), torch.randn(5, 4, generator=g)
 
 
-def _worker(rank, world, port, accumulation, outdir):
+def _worker(rank, world, port, accumulation, outdir, exchange="all_reduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from weed_instance_segmentation_amd.parallel import DataParallelEngine
     torch.manual_seed(1234 + rank)  # replicas start DIFFERENT; the engine must broadcast rank 0's
     model = Tiny()
-    eng = DataParallelEngine(model, lr=1e-2, accumulation=accumulation, bucket_bytes=600)  # several buckets
+    eng = DataParallelEngine(model, lr=1e-2, accumulation=accumulation, bucket_bytes=600, exchange=exchange)  # several buckets
     assert len(eng.buckets.buckets) > 2
     stepped = []
     for step in range(4):
@@ -73,10 +73,10 @@ def _reference(world, accumulation):
     return [p.detach().clone() for p in model.parameters()]
 
 
-def _run(accumulation, outdir):
+def _run(accumulation, outdir, exchange="all_reduce"):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, accumulation, str(outdir))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, accumulation, str(outdir), exchange)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -99,3 +99,9 @@ def test_ddp_gloo_world2(tmp_path):
 
 def test_ddp_gloo_world2_accumulation2(tmp_path):
     _run(2, tmp_path)  # the reference's GRADIENT_ACCUMULATION = 2 (config.py:8)
+
+
+def test_ddp_gloo_world2_reduce_scatter_form(tmp_path):
+    """exchange="reduce_scatter": buckets padded to whole shards; under gloo (no reduce_scatter_tensor) the exchange
+    object takes its all-reduce form -- same parameters either way."""
+    _run(2, tmp_path, exchange="reduce_scatter")

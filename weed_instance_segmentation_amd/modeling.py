@@ -407,6 +407,8 @@ class MaskedAttentionDecoder(nn.Module):
         self.mask_predictor = MaskPredictor(config.hidden_dim, config.num_attention_heads, config.mask_feature_size)
         # switch for A/B tests of the low-resolution attention-mask route (WM2F_LOW_RES_MASKS=0 turns it off at construction)
         self.low_res_masks = os.environ.get("WM2F_LOW_RES_MASKS", "1") != "0"
+        # tests: set to a list to receive every layer's attention-mask bytes (B, Q, HW_l) in order
+        self.record_attention_masks: list | None = None
 
     def forward(self, h, qpos, feats, poss, mask_features, sizes, need_all_logits=True):
         """need_all_logits=False (inference without auxiliary outputs): only the LAST prediction is computed at the
@@ -429,6 +431,8 @@ class MaskedAttentionDecoder(nn.Module):
             mask, row_open = self.mask_predictor.attention_mask_only(inter[0], pix_level[0], sizes[0])
         else:
             logits, mask, row_open = self.mask_predictor(inter[0], mask_features, sizes[0], pix_t)
+        if self.record_attention_masks is not None:
+            self.record_attention_masks.append(mask)
         all_logits = [logits]
         keys_in = [None, None, None]  # feats[lvl] + poss[lvl]: the same for the three layers that attend to a level
         for idx, layer in enumerate(self.layers):
@@ -448,6 +452,8 @@ class MaskedAttentionDecoder(nn.Module):
                 logits = ops.mask_einsum(self.mask_predictor.mask_embedder(inter[-1]), mask_features)
             else:
                 logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[nxt], pix_t)
+            if self.record_attention_masks is not None and idx + 1 < len(self.layers):
+                self.record_attention_masks.append(mask)
             all_logits.append(logits)
         return h, inter, all_logits
 

@@ -12,7 +12,15 @@ the path needs when the image batch is sharded over GPUs:
   * the loss normaliser `num_masks` is all-reduced like the dependency does under a distributed
     launch (HF:781-794): one scalar, before the per-level losses.
 
-Works with any backend (`nccl` == RCCL on ROCm; `gloo` for the CPU tests).
+Two forms of the bucket exchange (`exchange=`):
+  "all_reduce"      one `all_reduce(SUM)` per bucket (default; RCCL picks ring / direct by size);
+  "reduce_scatter"  `reduce_scatter_tensor` + `all_gather_into_tensor` per bucket -- the two halves of an all-reduce as
+                    separate collectives, each moving S/N per peer pair over all 7 xGMI links at once; the
+                    mean is taken on the 1/N shard between the two.  Unmeasured on hardware (no multi-GPU box in the
+                    build loop); same result as "all_reduce" (tests).
+
+Works with any backend (`nccl` == RCCL on ROCm; `gloo` for the tests: CPU tensors directly, GPU tensors staged through
+host memory, so that two ranks can share ONE GPU in tests/test_parallel_gpu.py -- RCCL refuses two ranks on a device).
 """
 from __future__ import annotations
 
@@ -23,10 +31,66 @@ import torch.distributed as dist
 from torch import nn
 
 
-class GradBuckets:
-    """Flat gradient storage with per-bucket async all-reduce."""
+class _Done:
+    def wait(self):
+        return True
 
-    def __init__(self, params: Iterable[nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None):
+
+def _host_staged(group) -> bool:
+    return dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+    """SUM all-reduce of `t` in place.  gloo + a GPU tensor: staged through host memory (tests only)."""
+    if t.is_cuda and _host_staged(group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return w if async_op else _Done()
+
+
+def broadcast_from(t: torch.Tensor, src: int = 0, group=None):
+    if t.is_cuda and _host_staged(group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
+class _ScatterGather:
+    """reduce_scatter_tensor -> mean on the shard -> all_gather_into_tensor, as one waitable exchange of a flat bucket
+    (its length is a multiple of the world size).  Backends without these collectives (gloo) take the all-reduce."""
+
+    def __init__(self, flat, world, group):
+        self.flat, self.world, self.group = flat, world, group
+        self.native = not _host_staged(group)
+        rank = dist.get_rank(group)
+        n = flat.numel() // world
+        self.shard = flat[rank * n:(rank + 1) * n]
+        self.work = (dist.reduce_scatter_tensor(self.shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                     if self.native else all_reduce_sum(flat, group))
+
+    def wait(self):
+        self.work.wait()
+        if self.native:
+            self.shard.div_(self.world)
+            dist.all_gather_into_tensor(self.flat, self.shard, group=self.group)
+        else:
+            self.flat.div_(self.world)
+        return True
+
+
+class GradBuckets:
+    """Flat gradient storage with per-bucket async exchange."""
+
+    def __init__(self, params: Iterable[nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None,
+                 exchange: str = "all_reduce"):
+        if exchange not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"exchange={exchange!r}")
+        self.exchange = exchange
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
@@ -50,7 +114,9 @@ class GradBuckets:
         self.sync_enabled = True
 
     def _close(self, ps):
-        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        n = sum(p.numel() for p in ps)
+        n = (n + self.world - 1) // self.world * self.world  # whole shards for the reduce-scatter form
+        flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
         off = 0
         for p in ps:
             p.grad = flat[off:off + p.numel()].view_as(p)
@@ -62,23 +128,32 @@ class GradBuckets:
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0 and self.sync_enabled:
-                self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._launch(b)
         return hook
+
+    def _launch(self, b):
+        b["sent"] = True
+        if self.exchange == "reduce_scatter":
+            self._handles.append(_ScatterGather(b["flat"], self.world, self.group))
+        else:
+            self._handles.append(all_reduce_sum(b["flat"], self.group, async_op=True))
 
     def finish(self):
         """Wait for every in-flight bucket, reduce stragglers (parameters that got no gradient this
         step never fire their hook), and turn sums into means."""
         if self.world > 1 and self.sync_enabled:
             for b in self.buckets:
-                if b["pending"] != 0:
-                    self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if not b.get("sent"):  # a parameter without a gradient this step: its hook never fired
+                    self._launch(b)
             for h in self._handles:
                 h.wait()
-            for b in self.buckets:
-                b["flat"].div_(self.world)
+            if self.exchange == "all_reduce":
+                for b in self.buckets:
+                    b["flat"].div_(self.world)
         self._handles.clear()
         for b in self.buckets:
             b["pending"] = len(b["params"])
+            b["sent"] = False
 
     def zero(self):
         for b in self.buckets:
@@ -93,15 +168,15 @@ class DataParallelEngine:
     all-reduce), optimiser step every `accumulation` calls -- the loop body of train.py:190-202."""
 
     def __init__(self, model: nn.Module, lr: float = 5e-5, accumulation: int = 1, bucket_bytes: int = 64 << 20,
-                 optimizer: torch.optim.Optimizer | None = None, process_group=None):
+                 optimizer: torch.optim.Optimizer | None = None, process_group=None, exchange: str = "all_reduce"):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.accumulation = max(1, int(accumulation))
         if self.world > 1:  # identical replicas: rank 0's weights and buffers win
             for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, src=0, group=process_group)
-        self.buckets = GradBuckets(model.parameters(), bucket_bytes, process_group)
+                broadcast_from(t.data, 0, process_group)
+        self.buckets = GradBuckets(model.parameters(), bucket_bytes, process_group, exchange)
         self.optimizer = optimizer or torch.optim.AdamW(model.parameters(), lr=lr)  # train.py:174
         self._micro = 0
         crit = getattr(model, "criterion", None)
@@ -111,7 +186,7 @@ class DataParallelEngine:
     def reduce_num_masks(self, n: torch.Tensor):
         """SUM over ranks of the per-rank target count, and the world size (HF:781-794)."""
         if self.world > 1:
-            dist.all_reduce(n, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(n, self.group)
         return n, self.world
 
     def backward_and_step(self, loss: torch.Tensor) -> bool:
