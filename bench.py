@@ -172,8 +172,9 @@ def main():
                        "parallelism": f"dp{world}", "mode": a.mode, "amp": a.amp},
         }
         # which route built the attention masks: named by the launches that actually ran
-        line["config"]["attention_masks"] = ("einsum at level resolution for the 9 intermediate predictions, full resolution "
-                                             "for the returned one" if any(k.startswith("mask_einsum_fwd_hw") for k in ksum)
+        line["config"]["attention_masks"] = ("einsum at level resolution for the 9 intermediate predictions "
+                                             "(mask bits from the MFMA epilogue, no logits written), full resolution for the returned one"
+                                             if any(k.startswith("mask_einsum_attn_mask") for k in ksum)
                                              else "every prediction at full resolution")
         # ---- roofline of the dominant hand-written kernel (K1) and of K3
         L, P, H, D, Q = 3, 4, 8, 32, 100

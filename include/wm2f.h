@@ -113,6 +113,15 @@ int wm2f_nchw_to_pixel_major_bf16(const void* src, void* dst, int B, int C, int 
 int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out, int B, int Q, int C, int HW,
                          int dtype, void* stream);
 
+/* K3 with the attention-mask epilogue fused (the `out_attn_mask` of SURVEY section 8b): HF:2046 followed by
+ * HF:2051-2053 (sigmoid, `< 0.5`) and the row flag of HF:1912-1914, for predictions that only feed the next layer's
+ * mask -- the logits are never written.  There is no resize in it: `pix` is the mask-feature map ALREADY resized to
+ * the level's resolution (wm2f_resize_bilinear once per forward; resize and einsum commute), so HW = Hn * Wn.
+ *   emb (B, Q, C)   pix (B, C, HW)   mask (B, Q, HW) uint8, 1 = blocked   row_open (B, Q) int32 (cleared by the call)
+ *   C % 16 == 0, HW % 4 == 0 */
+int wm2f_mask_einsum_attn_mask_fwd(const void* emb, const void* pix, void* mask, void* row_open, int B, int Q, int C,
+                                   int HW, int dtype, void* stream);
+
 /* ---- attention-mask build ----------------------------------------------------------------
  * Replaces HF:2048-2054 (bilinear resize, sigmoid, < 0.5) WITHOUT the x num_heads replication,
  * and the row fix-up of HF:1912-1914.

@@ -242,6 +242,63 @@ def test_k3_random(ops, B, Q, C, H, W):
     assert torch.equal(ops.mask_einsum(dev(emb_i), dev(pix_i)).cpu(), torch.einsum("bqc,bchw->bqhw", emb_i, pix_i))
 
 
+@pytest.mark.parametrize("B,Q,C,H,W", [(8, 100, 256, 32, 32), (8, 100, 256, 64, 64), (2, 100, 256, 128, 128), (1, 100, 256, 32, 32),
+                                       (2, 200, 256, 16, 24), (1, 37, 64, 5, 16), (3, 16, 32, 8, 8), (1, 5, 16, 2, 2),
+                                       (2, 100, 64, 32, 48), (1, 113, 128, 20, 36), (8, 100, 256, 8, 8)])
+def test_k3_fused_attention_mask_epilogue(ops, B, Q, C, H, W):
+    """wm2f_mask_einsum_attn_mask_fwd (HF:2046 + :2051-2053 + :1912-1914 in one launch, no logits written), over the
+    shapes that exercise every work split (1 / 2 / 4 / 6+4 / 7 row tiles per wave, 4- and 8-wave workgroups, ragged
+    strips and query tails).  Exact integer operands give exact logits, so every bit is decided: blocked <=> logit < 0
+    (a zero logit has sigmoid 0.5, which is not < 0.5).  Then real-valued operands against the two-launch route
+    (einsum, then threshold): equal wherever the logit is clear of the threshold."""
+    g = torch.Generator().manual_seed(B * 1000 + Q + H)
+    emb_i = torch.randint(-3, 4, (B, Q, C), generator=g).float()
+    pix_i = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
+    emb_i[0, min(3, Q - 1)] = 5.0
+    pix_i[0] = pix_i[0].abs() * -1.0 - 1.0 if B > 1 else pix_i[0]  # image 0 (when there are several): query 3 blocked everywhere
+    logits = torch.einsum("bqc,bchw->bqhw", emb_i, pix_i).flatten(2)
+    m, ro = ops.mask_einsum_attn_mask(dev(emb_i), dev(pix_i))
+    assert m.shape == (B, Q, H * W) and m.dtype == torch.uint8 and ro.shape == (B, Q) and ro.dtype == torch.int32
+    assert torch.equal(m.cpu().bool(), logits < 0)
+    assert torch.equal(ro.cpu().bool(), ~(logits < 0).all(-1))
+    if B > 1:
+        assert not bool(ro[0, min(3, Q - 1)])  # a fully blocked row was present
+    emb = torch.randn(B, Q, C, generator=g)
+    pix = torch.randn(B, C, H, W, generator=g)
+    lg = ops.mask_einsum(dev(emb), dev(pix))
+    m2, ro2 = ops.attn_mask_build(lg, (H, W))
+    m1, ro1 = ops.mask_einsum_attn_mask(dev(emb), dev(pix))
+    clear = (lg.flatten(2).abs() > 1e-5 * lg.abs().max()).cpu()
+    assert torch.equal(m1.cpu()[clear], m2.cpu()[clear])  # (the remainder rows take another summation order)
+    assert (m1 != m2).float().mean().item() < 1e-4
+    assert torch.equal(ro1.cpu().bool(), (m1 == 0).any(-1).cpu())
+
+
+def test_k3_fused_attention_mask_epilogue_golden(ops):
+    """The level-resolution route on the dependency's own vectors (k3_mask_predictor.npz): the mask features resized to
+    the target size (wm2f_resize_bilinear), then the fused einsum + threshold, against the masks the dependency made by
+    resizing its full-resolution logits (HF:2046-2054).  Resize and einsum commute in real arithmetic; in fp32 the two
+    orders differ by rounding, so bits may differ only where the dependency's resized logit is within 1e-4 of its range
+    of the threshold."""
+    g = load_golden("k3_mask_predictor.npz")
+    emb, pix, logits = dev(T(g["mask_embeddings"])), dev(T(g["pix"])), T(g["logits"])
+    n = 0
+    for i in range(5):
+        size = tuple(int(v) for v in g[f"size_{i}"])
+        if size[1] % 4:
+            continue  # the route needs widths divisible by 4 (the model falls back to the two-launch route otherwise)
+        n += 1
+        m, ro = ops.mask_einsum_attn_mask(emb, ops.resize_bilinear(pix, size))
+        exp = T(g[f"attn_mask_{i}"])
+        resized = torch.nn.functional.interpolate(logits, size=size, mode="bilinear", align_corners=False).flatten(2)
+        clear = resized.abs() > 1e-4 * resized.abs().max()
+        got = m.cpu().bool()
+        assert torch.equal(got[clear], exp[clear]), f"size {size}"
+        assert (got != exp).float().mean().item() < 1e-3
+        assert torch.equal(ro.cpu().bool(), ~got.all(-1))
+    assert n >= 2
+
+
 @pytest.mark.parametrize("B,Q,C,H,W", [(2, 100, 256, 64, 64), (1, 7, 64, 5, 13), (2, 200, 256, 16, 24), (1, 112, 32, 33, 8)])
 def test_k3_bf16(ops, B, Q, C, H, W):
     """bf16 operands on the bf16 matrix cores, fp32 accumulation and output: against the exact fp32 products of the

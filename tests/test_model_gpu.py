@@ -191,7 +191,7 @@ def test_low_resolution_attention_masks_equal_full_resolution_route(tiny):
                 o = model(pixel_values=x.cuda())
             torch.cuda.synchronize()
             wops.set_kernel_timer(None)
-            launches[low] = {k: n for k, (n, _) in timer.summary().items() if k.startswith("mask_einsum_fwd")}
+            launches[low] = {k: n for k, (n, _) in timer.summary().items() if k.startswith("mask_einsum")}
             assert o.auxiliary_logits is None
             outs[low] = (o.masks_queries_logits.cpu(), o.class_queries_logits.cpu())
     finally:
@@ -200,6 +200,7 @@ def test_low_resolution_attention_masks_equal_full_resolution_route(tiny):
     n_pred = len(dec.layers) + 1
     assert launches[False] == {"mask_einsum_fwd": n_pred}, launches  # every prediction at the mask-feature resolution
     assert launches[True]["mask_einsum_fwd"] == 1 and sum(launches[True].values()) == n_pred, launches  # one full, the rest per level
+    assert all(k.startswith("mask_einsum_attn_mask_hw") for k in launches[True] if k != "mask_einsum_fwd"), launches  # fused epilogue
     rm = ref["masks_queries_logits"]
     for low in (True, False):
         assert (outs[low][0] - rm).abs().max().item() / rm.abs().max().item() < 1e-3

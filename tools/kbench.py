@@ -130,6 +130,22 @@ def main():
             logits = ops.mask_einsum(emb, pix)
             for hw in shapes:
                 res[f"attn_mask_build_{hw[0]}"] = timeit(lambda: ops.attn_mask_build(logits, hw), a.iters)
+    if "k3m" in only:  # K3 with the fused attention-mask epilogue at the three level resolutions (the inference route)
+        emb = torch.randn(B, Q, 256, device=dev)
+        for hw in shapes:
+            pl = torch.randn(B, 256, hw[0], hw[1], device=dev)
+            flop = 2 * B * Q * 256 * hw[0] * hw[1]
+            r = timeit(lambda: ops.mask_einsum_attn_mask(emb, pl), a.iters)
+            r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6)
+            res[f"k3_fused_attn_mask_hw{hw[0] * hw[1]}"] = r
+            r = timeit(lambda: ops.attn_mask_build(ops.mask_einsum(emb, pl), hw), a.iters)
+            r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6)
+            res[f"k3_two_launch_route_hw{hw[0] * hw[1]}"] = r
+        pix = torch.randn(B, 256, 256, 256, device=dev)
+        for hw in shapes:
+            r = timeit(lambda: ops.resize_bilinear(pix, hw), a.iters)
+            r.update(bytes=4 * (pix.numel() + B * 256 * hw[0] * hw[1]))
+            res[f"resize_mask_features_to_{hw[0]}"] = r
     if "k3b" in only:  # K3 on the bf16 matrix cores (bf16 autocast path): HBM-bound
         emb = torch.randn(B, Q, 256, device=dev).to(torch.bfloat16)
         pix = torch.randn(B, 256, 256, 256, device=dev).to(torch.bfloat16)

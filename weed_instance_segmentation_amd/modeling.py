@@ -377,11 +377,14 @@ class MaskPredictor(nn.Module):
         self.mask_embedder = _mlp_head(hidden, hidden, mask_feature_size)
 
     def forward(self, h_norm, mask_features, next_size, pix_t=None):
-        """pix_t: the pixel-major bf16 copy of mask_features (bf16 autocast) -> K3 on the bf16 matrix cores."""
+        """pix_t: the pixel-major bf16 copy of mask_features (bf16 autocast) -> K3 on the bf16 matrix cores.
+        next_size None: the last prediction -- no layer is left to mask (the dependency builds that mask and drops it)."""
         if pix_t is not None:
             logits = ops.mask_einsum_bf16(self.mask_embedder(h_norm), mask_features, pix_t)
         else:
             logits = ops.mask_einsum(self.mask_embedder(h_norm), mask_features)
+        if next_size is None:
+            return logits, None, None
         mask, row_open = ops.attn_mask_build(logits, next_size)
         return logits, mask, row_open
 
@@ -389,10 +392,10 @@ class MaskPredictor(nn.Module):
         """The attention mask of the next layer WITHOUT the full-resolution logits (inference, when no caller sees the
         intermediate predictions).  HF:2046-2054 computes einsum(E, P) at the mask-feature resolution and resizes it
         bilinearly to the level's size; both are linear, so resize(einsum(E, P)) == einsum(E, resize(P)): `pix_level` is
-        the mask-feature map resized ONCE per forward to this level's size, and the einsum runs on 1/64 ... 1/4 of the
-        pixels.  The values differ from the full-resolution route by fp32 rounding only."""
-        logits = ops.mask_einsum(self.mask_embedder(h_norm), pix_level, tag=f"hw{size[0] * size[1]}")
-        return ops.attn_mask_build(logits, size)  # same size in and out: the bilinear resize inside is the identity
+        the mask-feature map resized ONCE per forward to this level's size, the einsum runs on 1/64 ... 1/4 of the
+        pixels, and its epilogue thresholds the accumulators straight into the mask bytes and the row flags -- the
+        logits are never written.  The values differ from the full-resolution route by fp32 rounding only."""
+        return ops.mask_einsum_attn_mask(self.mask_embedder(h_norm), pix_level, tag=f"hw{size[0] * size[1]}")
 
 
 class MaskedAttentionDecoder(nn.Module):
@@ -451,7 +454,8 @@ class MaskedAttentionDecoder(nn.Module):
             elif low:  # the prediction that is returned: full resolution, and no layer left to mask
                 logits = ops.mask_einsum(self.mask_predictor.mask_embedder(inter[-1]), mask_features)
             else:
-                logits, mask, row_open = self.mask_predictor(inter[-1], mask_features, sizes[nxt], pix_t)
+                logits, mask, row_open = self.mask_predictor(inter[-1], mask_features,
+                                                             sizes[nxt] if idx + 1 < len(self.layers) else None, pix_t)
             if self.record_attention_masks is not None and idx + 1 < len(self.layers):
                 self.record_attention_masks.append(mask)
             all_logits.append(logits)

@@ -278,6 +278,24 @@ def mask_einsum_bf16(emb: torch.Tensor, pix: torch.Tensor, pix_t: torch.Tensor) 
     return _MaskEinsumBf16.apply(emb, pix, pix_t)
 
 
+def mask_einsum_attn_mask(emb: torch.Tensor, pix_level: torch.Tensor, tag: str | None = None):
+    """K3 with the thresholding epilogue fused (HF:2046, :2051-2053, :1912-1914): emb (B,Q,C), pix_level (B,C,h,w) = the
+    mask features at the LEVEL's resolution -> (mask (B,Q,h*w) uint8 1 = blocked, row_open (B,Q) int32).  No logits are
+    written; no autograd (the dependency detaches the mask, HF:2054)."""
+    emb, pix_level = _req(_f32(emb.detach()), "emb"), _req(_f32(pix_level.detach()), "pix_level")
+    B, Q, C = emb.shape
+    if pix_level.dim() != 4 or pix_level.shape[0] != B or pix_level.shape[1] != C:
+        raise ValueError(f"mask_einsum_attn_mask: emb {tuple(emb.shape)} vs pix {tuple(pix_level.shape)}")
+    HW = int(pix_level.shape[2]) * int(pix_level.shape[3])
+    mask = torch.empty(B, Q, HW, device=emb.device, dtype=torch.uint8)
+    row_open = torch.empty(B, Q, device=emb.device, dtype=torch.int32)
+    with torch.cuda.device(emb.device):
+        check(_timed("mask_einsum_attn_mask" + (f"_{tag}" if tag else ""), emb, lambda: load().wm2f_mask_einsum_attn_mask_fwd(
+            _p(emb), _p(pix_level), _p(mask), _p(row_open), B, Q, C, HW, WM2F_F32, _stream(emb))),
+            "wm2f_mask_einsum_attn_mask_fwd")
+    return mask, row_open
+
+
 def attn_mask_build(logits: torch.Tensor, size: Sequence[int]):
     """HF:2048-2054 + HF:1912-1914: (mask (B,Q,Hn*Wn) uint8 1=blocked, row_open (B,Q) int32).  No grad."""
     logits = _req(_f32(logits.detach()), "logits")
