@@ -219,6 +219,10 @@ int wm2f_group_norm_tokens(const void* x, const void* bias, const void* gamma, c
  *                       align_corners=False) in fp32, Wo % 4 == 0 -- the resize of HF:2048-2050, applied to the mask
  *                       FEATURES once per level instead of to every layer's logits (resize and einsum commute). */
 int wm2f_resize_bilinear(const void* x, void* y, int NC, int H, int W, int Ho, int Wo, void* stream);
+/* wm2f_resize_pyramid: the same resize to (H/2, W/2), (H/4, W/4) and (H/8, W/8) in one pass over x (NC, H, W), H and W
+ *                      divisible by 8: y2 (NC, H/2, W/2), y4 (NC, H/4, W/4), y8 (NC, H/8, W/8), each bit for bit what
+ *                      wm2f_resize_bilinear gives for that size (at these ratios every output is the mean of a 2 x 2 block). */
+int wm2f_resize_pyramid(const void* x, void* y2, void* y4, void* y8, int NC, int H, int W, void* stream);
 /* wm2f_bias_relu_maxpool: y (N, C, H/2, W/2) = MaxPool2d(kernel 3, stride 2, padding 1)(ReLU(x + bias[c])), x (N, C, H, W)
  *                         fp32, H even, W % 8 == 0 -- the stem of transformers' ResNet embeddings
  *                         (modeling_resnet.py ResNetEmbeddings: convolution, normalization folded, ReLU, pooler). */

@@ -582,3 +582,21 @@ def test_cpu_tensor_is_refused(ops):
     from weed_instance_segmentation_amd._lib import Wm2fError
     with pytest.raises(Wm2fError):
         ops.mask_einsum(torch.randn(1, 4, 16), torch.randn(1, 16, 2, 2))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 64, 64), (1, 3, 8, 8), (2, 5, 24, 40), (1, 256, 256, 256), (3, 2, 16, 520)])
+def test_resize_pyramid_equals_three_bilinear_resizes(ops, N, C, H, W):
+    """wm2f_resize_pyramid: the 1/2, 1/4 and 1/8 size bilinear resizes in one pass -- bit for bit the generic kernel's
+    output for each size (2 x 2 means with weights exactly 0.5) and torch's CPU interpolate to round-off."""
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, C, H, W, generator=g) * 3.0
+    ys = ops.resize_pyramid(dev(x))
+    for k, y in zip((1, 2, 3), ys):
+        size = (H >> k, W >> k)
+        assert y.shape == (N, C, *size)
+        if size[1] % 4 == 0:
+            assert torch.equal(y, ops.resize_bilinear(dev(x), size))
+        ref = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.resize_pyramid(dev(torch.zeros(1, 1, 12, 16)))

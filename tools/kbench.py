@@ -142,6 +142,9 @@ def main():
             r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6)
             res[f"k3_two_launch_route_hw{hw[0] * hw[1]}"] = r
         pix = torch.randn(B, 256, 256, 256, device=dev)
+        r = timeit(lambda: ops.resize_pyramid(pix), a.iters)
+        r.update(bytes=4 * pix.numel() * 85 // 64, GBps=4 * pix.numel() * 85 / 64 / r["med_us"] / 1e3)
+        res["resize_pyramid_all_three"] = r
         for hw in shapes:
             r = timeit(lambda: ops.resize_bilinear(pix, hw), a.iters)
             r.update(bytes=4 * (pix.numel() + B * 256 * hw[0] * hw[1]))

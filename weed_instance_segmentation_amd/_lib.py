@@ -58,6 +58,7 @@ SIGNATURES = {
     "wm2f_tokens_to_nchw": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_group_norm_tokens": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, c_float, _P]),
     "wm2f_resize_bilinear": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm2f_resize_pyramid": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "wm2f_bias_relu_maxpool": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_group_norm_act": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_float, _I, _P]),
     "wm2f_point_sample_fwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -505,3 +505,63 @@ extern "C" int wm2f_resize_bilinear(const void* x, void* y, int NC, int H, int W
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// The three attention-mask resolutions in ONE pass over the mask features.  For output sizes that are exactly 1/2, 1/4 and
+// 1/8 of the input, PyTorch's source-index rule gives src = s * (dst + 0.5) - 0.5 = s * dst + (s - 1) / 2: the two taps
+// are input rows / columns 2d, 2d+1 (s = 2), 4d+1, 4d+2 (s = 4), 8d+3, 8d+4 (s = 8), all with weights exactly 0.5 -- each
+// output is the mean of a 2 x 2 block, bit for bit what wm2f_resize_bilinear (and torch) computes, because scaling by 0.5
+// is exact.  A thread owns 4 consecutive columns x 8 rows of one map (eight fully coalesced 16-byte loads) and writes 2 x 4
+// outputs of the half-size map, 1 x 2 of the quarter-size map and, together with its right-hand neighbour (columns
+// 8d+3 | 8d+4 sit in different threads: one DPP move), 1 of the eighth-size map.  HBM-bound: reads the map once
+// (537 MB at config 2), writes 21/64 of it.
+namespace wm2f {
+namespace {
+__device__ __forceinline__ float mean4(float a, float b, float c, float d) { return 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * c + 0.5f * d); }
+
+__global__ __launch_bounds__(256) void resize_pyramid_kernel(const float* __restrict__ x, float* __restrict__ y2, float* __restrict__ y4,
+                                                             float* __restrict__ y8, int H, int W, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (map, 8-row block, 4-column block)
+  const bool live = t < total;
+  const int W4 = W >> 2, H8 = H >> 3;
+  const int64_t tt = live ? t : 0;
+  const int cx = (int)(tt % W4);
+  const int64_t r = tt / W4;
+  const int by = (int)(r % H8);
+  const int64_t nc = r / H8;
+  const float* src = x + (nc * H + (int64_t)by * 8) * W + cx * 4;
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(src + (int64_t)i * W);
+  const int W2 = W >> 1, Wq = W >> 2, We = W >> 3;
+  if (live) {
+    float* d2 = y2 + (nc * (H >> 1) + (int64_t)by * 4) * W2 + cx * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float2*>(d2 + (int64_t)i * W2) = make_float2(mean4(v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y),
+                                                                    mean4(v[2 * i].z, v[2 * i].w, v[2 * i + 1].z, v[2 * i + 1].w));
+    float* d4 = y4 + (nc * (H >> 2) + (int64_t)by * 2) * Wq + cx;
+    d4[0] = mean4(v[1].y, v[1].z, v[2].y, v[2].z);
+    d4[Wq] = mean4(v[5].y, v[5].z, v[6].y, v[6].z);
+  }
+  // eighth size: rows 8d+3, 8d+4 = v[3], v[4]; columns 8d+3 (this thread's .w when cx is even) and 8d+4 (the right-hand
+  // neighbour's .x).  W % 8 == 0 keeps an even thread and its neighbour in one row; 256 | blockDim keeps them in one wave.
+  const float nx3 = __shfl_down(v[3].x, 1, 64), nx4 = __shfl_down(v[4].x, 1, 64);
+  if (live && (cx & 1) == 0) y8[(nc * (H >> 3) + by) * We + (cx >> 1)] = mean4(v[3].w, nx3, v[4].w, nx4);
+}
+}  // namespace
+}  // namespace wm2f
+
+extern "C" int wm2f_resize_pyramid(const void* x, void* y2, void* y4, void* y8, int NC, int H, int W, void* stream) {
+  using namespace wm2f;
+  const char* who = "wm2f_resize_pyramid";
+  WM2F_REQUIRE(x && y2 && y4 && y8, "%s: null pointer", who);
+  WM2F_REQUIRE(NC > 0 && H > 0 && W > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(H % 8 == 0 && W % 8 == 0, "%s: needs H and W divisible by 8 (got %d x %d)", who, H, W);
+  const int64_t total = (int64_t)NC * (H / 8) * (W / 4);
+  WM2F_REQUIRE(ceil_div64(total, 256) < (int64_t(1) << 31), "%s: sizes exceed the grid limits", who);
+  hipLaunchKernelGGL(resize_pyramid_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x, (float*)y2, (float*)y4, (float*)y8, H, W, total);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}

@@ -427,7 +427,14 @@ class MaskedAttentionDecoder(nn.Module):
         low = (not need_all_logits and self.low_res_masks and not torch.is_grad_enabled() and pix_t is None
                and mask_features.is_cuda and mask_features.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
                and all(ww % 4 == 0 for hh, ww in sizes))
-        pix_level = [ops.resize_bilinear(mask_features.contiguous(), s) for s in sizes] if low else None
+        pix_level = None
+        if low:
+            mf = mask_features.contiguous()
+            Hm, Wm = int(mf.shape[2]), int(mf.shape[3])
+            if Hm % 8 == 0 and Wm % 8 == 0 and list(sizes) == [(Hm >> 3, Wm >> 3), (Hm >> 2, Wm >> 2), (Hm >> 1, Wm >> 1)]:
+                pix_level = ops.resize_pyramid(mf)[::-1]  # the usual strides 32 / 16 / 8 against 4: one pass for all three
+            else:
+                pix_level = [ops.resize_bilinear(mf, s) for s in sizes]
         inter = [self.layernorm(h)]
         if low:
             logits = None

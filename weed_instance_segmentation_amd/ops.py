@@ -542,6 +542,22 @@ def resize_bilinear(x: torch.Tensor, size: Sequence[int]) -> torch.Tensor:
     return y
 
 
+def resize_pyramid(x: torch.Tensor):
+    """(half, quarter, eighth)-size bilinear resizes of an NCHW fp32 map in ONE pass (H, W divisible by 8): bit for bit
+    `resize_bilinear(x, (H/2, W/2))`, `(H/4, W/4)`, `(H/8, W/8)`.  Inference, no autograd."""
+    if not x.is_contiguous():
+        raise ValueError("resize_pyramid: x must be NCHW-contiguous")
+    _req(x, "x")
+    N, C, H, W = x.shape
+    if H % 8 or W % 8:
+        raise ValueError("resize_pyramid: H and W must be divisible by 8")
+    ys = [torch.empty(N, C, H >> k, W >> k, device=x.device, dtype=torch.float32) for k in (1, 2, 3)]
+    with torch.cuda.device(x.device):
+        check(_timed("resize_pyramid", x, lambda: load().wm2f_resize_pyramid(_p(x), _p(ys[0]), _p(ys[1]), _p(ys[2]), N * C, H, W, _stream(x))),
+              "wm2f_resize_pyramid")
+    return ys
+
+
 def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """MaxPool2d(3, 2, 1)(ReLU(x + bias[c])) of an NCHW map in one pass (inference, no autograd): the ResNet stem tail."""
     if not x.is_contiguous():
