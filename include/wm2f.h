@@ -88,6 +88,7 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
  *           3: phased quad kernel (3 levels with sides 1:2:4 coarse first, P = 4, D = 32, margin 4)
  *           4: streaming quad kernel (same shapes; persistent workgroups + loader waves)
  *           5: streaming quad kernel with per-window flags instead of workgroup barriers
+ *           6: streaming quad kernel walking the tiles of an image in raster order (4 and 5: 2-wide vertical strips)
  *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that
  *           from their reference point take a slow path (results never depend on it).
  * Any other variant returns WM2F_EUNSUPPORTED: timing ablations and stamped builds live in the separate profiling

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--only", default="k1,k1f,k3,mask,k2,k4")
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--smooth", action="store_true", help="K1: slowly varying offsets instead of independent uniform ones")
+    ap.add_argument("--init", action="store_true", help="K1: the module's initial offset pattern (point i of head h sits (i + 1) px along direction h, HF:2154-2166) -- what bench.py's random-init model feeds the kernel")
     ap.add_argument("--prof", action="store_true", help="load libwm2f_prof.so: K1 timing ablations (variant 44 ...), WM2F_K2_* / WM2F_K3_DBG environment knobs")
     a = ap.parse_args()
     if a.prof:
@@ -55,6 +56,12 @@ def main():
             pos = ref[None, :, None, None, None, :] * 6.283
             ph = torch.rand(1, 1, H, L, P, 2, device=dev) * 6.283
             off = 3.5 * torch.sin(pos * torch.tensor([1.0, 1.7], device=dev) + ph) + 0.1 * torch.randn(B, S, H, L, P, 2, device=dev)
+        if a.init:
+            th = torch.arange(H, device=dev, dtype=torch.float32) * (2.0 * 3.141592653589793 / H)
+            grid = torch.stack([th.cos(), th.sin()], -1)
+            grid = grid / grid.abs().max(-1, keepdim=True)[0]
+            off = (grid[None, None, :, None, None, :] * torch.arange(1, P + 1, device=dev, dtype=torch.float32)[None, None, None, None, :, None]
+                   ).expand(B, S, H, L, P, 2).contiguous()
         norm = torch.tensor([[w, h] for h, w in shapes], device=dev, dtype=torch.float32)
         loc = (ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
         logits = torch.randn(B, S, H, L * P, device=dev)
@@ -73,6 +80,15 @@ def main():
                 r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=variant, margin=margin), a.iters)
                 r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
                 res[f"k1_fused_variant{variant}_margin{margin}"] = r
+        if "k1o" in only:  # tile work order of the streaming kernel: 2-wide strips (4) against raster (6), interleaved rounds
+            fns = {v: (lambda v=v: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=v, margin=4)) for v in (4, 6)}
+            rounds = {v: [] for v in fns}
+            for _ in range(5):
+                for v, fn in fns.items():
+                    rounds[v].append(timeit(fn, a.iters)["med_us"])
+            for v in fns:
+                ts = sorted(rounds[v])
+                res[f"k1_fused_variant{v}_rounds"] = dict(min_us=ts[0], med_us=ts[len(ts) // 2], GBps=nbytes / ts[len(ts) // 2] / 1e3)
         if "k1b" in only:  # backward
             vv, ll, ww_ = value.clone().requires_grad_(), loc.clone().requires_grad_(), aw.clone().requires_grad_()
             go = torch.randn(B, S, H * D, device=dev)

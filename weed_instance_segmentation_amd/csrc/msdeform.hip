@@ -280,6 +280,7 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
 //          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations;
 //          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads;
 //          5 = streaming kernel with per-window flags instead of workgroup barriers
+//          6 = streaming kernel walking the tiles in raster order (default: 2-wide vertical strips)
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -292,17 +293,18 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
 #ifndef WM2F_PROFILING
   // the production library launches only kernels whose outputs are valid: 0 auto, 1 direct gather, 2 LDS windows,
-  // 3 phased quads, 4 streaming quads, 5 streaming with flags, 62 LDS windows in slab-major order
-  if (!(variant >= 0 && variant <= 5) && variant != 62) {
+  // 3 phased quads, 4 streaming quads, 5 streaming with flags, 6 streaming in raster tile order, 62 LDS windows in
+  // slab-major order
+  if (!(variant >= 0 && variant <= 6) && variant != 62) {
     set_error("%s: variant %d is a timing ablation / stamped build: profiling library only (libwm2f_prof.so, "
               "include/wm2f_prof.h)", who, variant);
     return WM2F_EUNSUPPORTED;
   }
 #endif
-  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || variant == 5)) {
+  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || variant == 5 || variant == 6)) {
     bool handled = false;
     if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
-                                      variant == 5 ? 100 : variant / 10, 0, 0))
+                                      variant == 5 ? 100 : (variant == 6 ? 200 : variant / 10), 0, 0))
       return rc;
     if (handled) return WM2F_OK;
     if (variant != 0) {

@@ -53,8 +53,8 @@ struct QuadGeom {
 // The stamp buffer -- the library's only device global -- and every ablation / stamped instantiation exist in the
 // PROFILING build alone (libwm2f_prof.so, -DWM2F_PROFILING, include/wm2f_prof.h); the production library carries
 // MODE 0 kernels only and no global mutable state.
-constexpr int kStampSlots = 16, kStampGroups = 8192;
 #ifdef WM2F_PROFILING
+constexpr int kStampSlots = 16, kStampGroups = 8192;
 __device__ long long g_stamps[kStampGroups * kStampSlots];
 #define WM2F_STAMP(k)                                                                  \
   do {                                                                                 \
@@ -572,6 +572,15 @@ struct StreamGeom {
   QuadGeom q;
   int n_logical, per_xcd, wg_per_xcd;
   float inv_heads, inv_ntiles, inv_tiles_x;
+  // a workgroup's next tile is `wg_per_xcd` ids further: (step_t tiles, step_h heads) with heads innermost
+  int step_t, step_h;
+  // work order of the tiles of one image: vertical strips `strip_w` tiles wide, walked row by row (0 = plain raster).
+  // An XCD holds 32 workgroups = 4 tiles x 8 heads at a time and its L2 (4 MiB) about three tiles' windows, so in
+  // raster order the 10 halo rows a tile row shares with the next one are long gone when that row comes round
+  // (2 x 8 x 1.2 MB later); in 2-wide strips the row below follows 2 tiles later and finds them in L2, and only the
+  // strip seams (3 per image instead of 7 tile-row seams) are fetched twice.
+  int strip_w, full_strips, rem_w;
+  float inv_per_strip, inv_strip_w, inv_rem_w;
 };
 
 // exact floor(a / d) for 0 <= a < 2^22 with inv ~ 1/d (one correction step either way)
@@ -586,15 +595,54 @@ __device__ __forceinline__ int div_small(int a, int d, float inv) {
 struct TileId {
   int b, h, tx, ty;
 };
-__device__ __forceinline__ TileId decode_tile(int id, const StreamGeom& sg, int heads) {
-  TileId t;
+
+// Position of a persistent workgroup in its tile sequence (all wave-uniform): image, head, and the tile's index within
+// the image in WORK order.  One division chain at the start, then additions.
+struct TileWalk {
+  int b, h, tile;
+};
+__device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int heads) {
+  TileWalk w;
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
   const int bt = div_small(id, heads, sg.inv_heads);
-  t.h = id - bt * heads;
-  t.b = div_small(bt, n_tiles, sg.inv_ntiles);
-  const int tile = bt - t.b * n_tiles;
-  t.ty = div_small(tile, sg.q.tiles_x, sg.inv_tiles_x);
-  t.tx = tile - t.ty * sg.q.tiles_x;
+  w.h = id - bt * heads;
+  w.b = div_small(bt, n_tiles, sg.inv_ntiles);
+  w.tile = bt - w.b * n_tiles;
+  return w;
+}
+__device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int heads) {
+  const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
+  w.h += sg.step_h;
+  if (w.h >= heads) {
+    w.h -= heads;
+    ++w.tile;
+  }
+  w.tile += sg.step_t;
+  while (w.tile >= n_tiles) {
+    w.tile -= n_tiles;
+    ++w.b;
+  }
+}
+__device__ __forceinline__ TileId walk_tile(const TileWalk& w, const StreamGeom& sg) {
+  TileId t;
+  t.b = w.b;
+  t.h = w.h;
+  if (sg.strip_w <= 0) {
+    t.ty = div_small(w.tile, sg.q.tiles_x, sg.inv_tiles_x);
+    t.tx = w.tile - t.ty * sg.q.tiles_x;
+    return t;
+  }
+  const int per_strip = sg.strip_w * sg.q.tiles_y;
+  int s = div_small(w.tile, per_strip, sg.inv_per_strip);
+  if (s >= sg.full_strips) {  // the narrower last strip (tiles_x not a multiple of strip_w)
+    const int r = w.tile - sg.full_strips * per_strip;
+    t.ty = div_small(r, sg.rem_w, sg.inv_rem_w);
+    t.tx = sg.full_strips * sg.strip_w + (r - t.ty * sg.rem_w);
+    return t;
+  }
+  const int r = w.tile - s * per_strip;
+  t.ty = div_small(r, sg.strip_w, sg.inv_strip_w);
+  t.tx = s * sg.strip_w + (r - t.ty * sg.strip_w);
   return t;
 }
 
@@ -655,9 +703,8 @@ struct LoaderTile {  // wave-uniform per-tile values of the loaders
   bool x_border;
 };
 
-__device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, int id, int S, int heads) {
+__device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, const TileId& t, int S, int heads) {
   const QuadGeom& g = sg.q;
-  const TileId t = decode_tile(id, sg, heads);
   const int row_stride = heads * 32, row_bytes = row_stride * 4, px0 = g.W0 * g.H0;
   const float* vb = value + ((int64_t)t.b * S * heads + t.h) * 32;
   LoaderTile lt;
@@ -676,10 +723,17 @@ __device__ __forceinline__ LoaderTile loader_tile(const float* value, const Stre
   return lt;
 }
 
-// What a gather lane knows about "its" queries for one tile shape (counts of queries per level in the tile),
-// packed: level (2 bits) | column in the tile (6 bits) | row in the tile (6 bits).
-struct Decode {
-  int code[kPasses];
+// What a gather lane knows about "its" queries for one tile SHAPE (the numbers of queries per level in the tile: the
+// same for every interior tile), so that a tile costs a handful of instructions per pass instead of a decode:
+//   q_rel     row * W_lq + col of the query inside its own level, relative to the tile's first query of that level
+//   lq        the query's level (0 coarse .. 2 fine)
+//   cxs, cys  (col + 0.5) * 2^-lq, (row + 0.5) * 2^-lq: its reference point in COARSE-level pixels relative to the tile
+// With the tile's per-level first query (3 scalars) the token is q_rel + first[lq]; on level l the reference point sits
+// at pixel (tx * 4 * 2^l) + (cxs * 2^l - 0.5) -- both exact in fp32 (integers and eighths), so the sampling coordinate
+// `that + offset` is rounded once (the dependency rounds (q + 0.5) / W, + offset / W and * W - 0.5 in turn).
+struct PassConst {
+  int q_rel[kPasses], lq[kPasses];
+  float cxs[kPasses], cys[kPasses];
   bool valid[kPasses];
 };
 
@@ -722,7 +776,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
   const int xcd = blockIdx.x % kNumXcd, lw = blockIdx.x / kNumXcd;
   const int range_end = min((xcd + 1) * sg.per_xcd, sg.n_logical) - xcd * sg.per_xcd;  // ids of this XCD: [0, range_end)
   const int n_my = lw < range_end ? (range_end - lw + sg.wg_per_xcd - 1) / sg.wg_per_xcd : 0;
-  const int first = xcd * sg.per_xcd + lw, stride = sg.wg_per_xcd;
+  const int first = xcd * sg.per_xcd + lw;
   if (n_my <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row_stride = heads * D, row_bytes = row_stride * 4;
@@ -749,7 +803,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     //   under the mid gather:               F(k) part B, coarse(k + 1)       (17 + 13)
     //   under the fine gather:              [pause: the gather waves fetch their next operands]  mid(k + 1)  (21)
     constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
-    LoaderTile lt = loader_tile(value, sg, first, S, heads);
+    TileWalk walk = walk_init(first, sg, heads);
+    LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
     loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
     __builtin_amdgcn_sched_barrier(0);
     loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
@@ -764,7 +819,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
         wait_vm<0>();
         publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
         if (k + 1 < n_my) {
-          lt = loader_tile(value, sg, first + (k + 1) * stride, S, heads);
+          walk_step(walk, sg, heads);
+          lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
           poll_ge(&ctrl[kCtrlDone + 0], kGatherWaves * (k + 1));
           loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
           __builtin_amdgcn_sched_barrier(0);
@@ -787,7 +843,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       WM2F_SSTAMP(13, kLoaderWave0);
       loader_issue<2, kFA, LWin<2>::n>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
       if (more) {
-        lt = loader_tile(value, sg, first + (k + 1) * stride, S, heads);
+        walk_step(walk, sg, heads);
+        lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
         __builtin_amdgcn_sched_barrier(0);
         loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
         wait_vm<LWin<0>::n>();  // fine(k) landed
@@ -817,17 +874,17 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
   const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
   const float inv_w0 = __builtin_amdgcn_rcpf((float)g.W0), inv_h0 = __builtin_amdgcn_rcpf((float)g.H0);
 
-  Decode dc;
-  int shape_key = -1;  // packed (nqx, nqy) per level of the tile shape `dc` was built for
+  PassConst pc;
+  int shape_key = -1;  // packed (nqx, nqy) per level of the tile shape `pc` was built for
   // operands of a tile: raw loads + where they go
   struct Ops {
     float2 lc[kPasses][NL];
     float wt[kPasses][NL];
-    int qrow[kPasses];
+    int qrow[kPasses];  // b * Q + token
     bool valid[kPasses];
     int wx0[NL], wy0[NL], b, h, tx, ty;
   };
-  // reference point of token q (HF:1127-1156): ((column + 0.5) / W_l, (row + 0.5) / H_l) of its own level
+  // reference point of token q (HF:1127-1156): ((column + 0.5) / W_l, (row + 0.5) / H_l) of its own level (slow path only)
   auto ref_point = [&](int q, float& rx, float& ry) __attribute__((always_inline)) {
     const int l = (q >= g.start[1] ? 1 : 0) + (q >= g.start[2] ? 1 : 0);
     const int rel = q - (l == 2 ? g.start[2] : (l == 1 ? g.start[1] : 0));
@@ -839,14 +896,14 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     rx = ((float)qx + 0.5f) * (inv_w0 * sc);
     ry = ((float)qyc + 0.5f) * (inv_h0 * sc);
   };
-  auto fetch = [&](int id) __attribute__((always_inline)) {
+  const int a_row = g.a_qstride * 4, b_row = g.b_qstride * 4;  // bytes per token in the two operand arrays (< 2^24: host)
+  auto fetch = [&](const TileId& t) __attribute__((always_inline)) {
     Ops o;
-    const TileId t = decode_tile(id, sg, heads);
     o.b = t.b;
     o.h = t.h;
     o.tx = t.tx;
     o.ty = t.ty;
-    int nqx[NL], nqy[NL], key = 0;
+    int nqx[NL], nqy[NL], qfirst[NL], key = 0;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
@@ -856,6 +913,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       nqx[l] = nx < 0 ? 0 : (nx > fq ? fq : nx);
       nqy[l] = ny < 0 ? 0 : (ny > fq ? fq : ny);
       key = key * 1024 + nqx[l] * 32 + nqy[l];
+      qfirst[l] = t.b * Q + g.start[l] + (t.ty * fq) * Wl + t.tx * fq;  // the tile's first token of level l
     }
     if (key != shape_key) {  // wave-uniform; interior tiles all share one shape
       shape_key = key;
@@ -868,27 +926,30 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
         // With 10 gather waves two passes cover 320 queries and wave 2 takes the last 16.
         const int w3 = kGatherWaves == 8 ? (wave < 4 ? wave : (wave == 7 ? 4 : 1 << 20)) : (wave == 2 ? 0 : 1 << 20);
         int qi = t2 < 2 ? slot + (kGatherWaves * 16) * t2 : 2 * (kGatherWaves * 16) + w3 * 16 + (quad & 8) + xq;
-        dc.valid[t2] = qi < nq;
-        if (!dc.valid[t2]) qi = 0;
+        pc.valid[t2] = qi < nq;
+        if (!pc.valid[t2]) qi = 0;  // an empty slot shadows the tile's first query (a real token: loads stay in range)
         const bool ge1 = qi >= c1, ge2 = qi >= c2;
+        const int lq = (ge1 ? 1 : 0) + (ge2 ? 1 : 0);
         const int nx = ge2 ? nqx[2] : (ge1 ? nqx[1] : nqx[0]);
         const int loc_i = qi - (ge2 ? c2 : (ge1 ? c1 : 0));
         const int nxs = nx < 1 ? 1 : nx;
         const int ly_ = (int)(((float)loc_i + 0.5f) * __builtin_amdgcn_rcpf((float)nxs));  // exact: small integers
-        dc.code[t2] = ((ge1 ? 1 : 0) + (ge2 ? 1 : 0)) | ((loc_i - ly_ * nxs) << 2) | (ly_ << 8);
+        const int lx_ = loc_i - ly_ * nxs;
+        const float sc = ge2 ? 0.25f : (ge1 ? 0.5f : 1.f);
+        pc.lq[t2] = lq;
+        pc.q_rel[t2] = (int)__umul24((unsigned)ly_, (unsigned)(g.W0 << lq)) + lx_;
+        pc.cxs[t2] = ((float)lx_ + 0.5f) * sc;
+        pc.cys[t2] = ((float)ly_ + 0.5f) * sc;
       }
     }
+    const int ah = (t.h * (NL * P * 2) + j * 2) * 4, bh = (t.h * (NL * P) + j) * 4;
 #pragma unroll
     for (int t2 = 0; t2 < kPasses; ++t2) {
-      const int sh = dc.code[t2] & 3;
-      const int qxi = (t.tx << (sh + 2)) + ((dc.code[t2] >> 2) & 63), qyi = (t.ty << (sh + 2)) + (dc.code[t2] >> 8);
-      const int st = sh == 2 ? g.start[2] : (sh == 1 ? g.start[1] : 0);
-      int q = st + (int)(__umul24((unsigned)qyi, (unsigned)g.W0) << sh) + qxi;
-      if (q > Q - 1) q = Q - 1;
-      o.valid[t2] = dc.valid[t2];
-      o.qrow[t2] = t.b * Q + q;
-      const int a_off = (o.qrow[t2] * g.a_qstride + t.h * (NL * P * 2) + j * 2) * 4;
-      const int b_off = (o.qrow[t2] * g.b_qstride + t.h * (NL * P) + j) * 4;
+      const int q = pc.q_rel[t2] + (pc.lq[t2] == 2 ? qfirst[2] : (pc.lq[t2] == 1 ? qfirst[1] : qfirst[0]));
+      o.valid[t2] = pc.valid[t2];
+      o.qrow[t2] = q;
+      const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
+      const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
         o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, 0));
@@ -898,7 +959,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     return o;
   };
 
-  Ops nxt = fetch(first);
+  TileWalk walk = walk_init(first, sg, heads);
+  Ops nxt = fetch(walk_tile(walk, sg));
   for (int k = 0; k < n_my; ++k) {
     Ops cur = nxt;
     WM2F_SSTAMP(0, 0);
@@ -906,13 +968,6 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     float px[kPasses][NL], py[kPasses][NL], wt[kPasses][NL];
 #pragma unroll
     for (int t = 0; t < kPasses; ++t) {
-      float refx = 0.f, refy = 0.f;
-      if (FUSED) {  // `dc` still describes this tile here: the next fetch (which may rebuild it) comes later
-        const int sh = dc.code[t] & 3;
-        const float sc = sh == 2 ? 0.25f : (sh == 1 ? 0.5f : 1.f);  // exact: rcp(W0 * 2^sh) == rcp(W0) * 2^-sh
-        refx = ((float)((cur.tx << (sh + 2)) + ((dc.code[t] >> 2) & 63)) + 0.5f) * (inv_w0 * sc);
-        refy = ((float)((cur.ty << (sh + 2)) + (dc.code[t] >> 8)) + 0.5f) * (inv_h0 * sc);
-      }
 #pragma unroll
       for (int l = 0; l < NL; ++l) wt[t][l] = cur.wt[t][l];
       if (FUSED) {  // softmax over the 12 logits of the quad (HF:986-991)
@@ -929,11 +984,13 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        const float Wl = (float)(g.W0 << l), Hl = (float)(g.H0 << l);
         if (FUSED) {
-          px[t][l] = (refx * Wl - 0.5f) + cur.lc[t][l].x;
-          py[t][l] = (refy * Hl - 0.5f) + cur.lc[t][l].y;
+          // loc = ref + off / (W, H); pixel = loc * (W, H) - 0.5 == ref * W - 0.5 + off, with ref * W - 0.5 taken
+          // exactly: tile origin + (cxs * 2^l - 0.5) (`pc` still describes this tile: the next fetch comes later)
+          px[t][l] = ((float)(cur.tx << (l + 2)) + fmaf(pc.cxs[t], (float)(1 << l), -0.5f)) + cur.lc[t][l].x;
+          py[t][l] = ((float)(cur.ty << (l + 2)) + fmaf(pc.cys[t], (float)(1 << l), -0.5f)) + cur.lc[t][l].y;
         } else {
+          const float Wl = (float)(g.W0 << l), Hl = (float)(g.H0 << l);
           px[t][l] = ((2.f * cur.lc[t][l].x - 1.f + 1.f) * Wl - 1.f) * 0.5f;
           py[t][l] = ((2.f * cur.lc[t][l].y - 1.f + 1.f) * Hl - 1.f) * 0.5f;
         }
@@ -969,7 +1026,10 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     WM2F_SSTAMP(5, 0);
     window_ready(2);  // Bf(k)
     WM2F_SSTAMP(6, 0);
-    if (k + 1 < n_my) nxt = fetch(first + (k + 1) * stride);  // lands under the fine gather
+    if (k + 1 < n_my) {  // lands under the fine gather
+      walk_step(walk, sg, heads);
+      nxt = fetch(walk_tile(walk, sg));
+    }
     __builtin_amdgcn_sched_barrier(0);
     WM2F_SSTAMP(7, 0);
     gather_phase<2, MODE, true>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
@@ -1106,7 +1166,8 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
   const int64_t n_logical = (int64_t)B * heads * g.tiles_x * g.tiles_y;
   const int64_t lim = 0x7fffffff;
-  if (n_logical >= (1 << 22) || (int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
+  if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || g.b_qstride * 4 >= (1 << 24) ||
+      (int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
       (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)16 * H0 * W0 >= (1 << 24) || heads * 32 * 4 >= (1 << 24) ||
       (int64_t)21 * H0 * W0 * heads * 32 * 4 >= lim)
     return WM2F_OK;
@@ -1130,12 +1191,22 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_heads = 1.f / (float)heads;
   sg.inv_ntiles = 1.f / (float)(g.tiles_x * g.tiles_y);
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
+  sg.step_t = sg.wg_per_xcd / heads;
+  sg.step_h = sg.wg_per_xcd % heads;
+  // tile work order inside an image: 2-wide vertical strips (see StreamGeom); mode 200 = plain raster (A/B measurement)
+  sg.strip_w = (mode == 200 || g.tiles_x < 2) ? 0 : 2;
+  sg.full_strips = sg.strip_w ? g.tiles_x / sg.strip_w : 0;
+  sg.rem_w = sg.strip_w ? g.tiles_x - sg.full_strips * sg.strip_w : 0;
+  sg.inv_per_strip = sg.strip_w ? 1.f / (float)(sg.strip_w * g.tiles_y) : 0.f;
+  sg.inv_strip_w = sg.strip_w ? 1.f / (float)sg.strip_w : 0.f;
+  sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
   auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0>;
 #ifdef WM2F_PROFILING
   if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0>;
   if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0>;
 #endif
   if (mode == 100) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1>;  // flags instead of barriers
+  // (mode 200: the same kernel as mode 0, raster tile order -- set above)
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(kSThreads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();
