@@ -80,6 +80,17 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
                                    const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L,
                                    int P, int dtype, int margin, void* stream);
 
+/* The same for rows in LANE-MAJOR order -- a free choice of the row order of the merged Linear that writes them, made for
+ * the kernel's loads: per token and head, the four sampling-point slots j = 0..3 (the kernel's lanes) one after the other,
+ * each as 9 floats [x y of level 0 | x y of level 1 | x y of level 2 | logit of level 0, 1, 2]:
+ *   lanes (B, Q, heads * 4 * 9):  lanes[.., h*36 + j*9 + 2*l + {0,1}] = offsets[.., h, l, j, {x,y}],
+ *                                 lanes[.., h*36 + j*9 + 6 + l]       = logits[.., h, l*4 + j]
+ * A lane then fetches its 36 contiguous bytes per query (3 loads, quad footprint 144 B) instead of 6 loads scattered over
+ * the 1152-byte row.  Streaming kernel only (D = 32, P = 4, L = 3 with sides 1:2:4 coarse first, Q == S); any other shape
+ * returns WM2F_EUNSUPPORTED (use the [offsets | logits] form). */
+int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* out, const int32_t* level_hw, int B, int S,
+                                  int Q, int heads, int D, int L, int P, int dtype, void* stream);
+
 /* Same two operations with the kernel variant exposed (A/B measurement of kernels whose OUTPUTS ARE ALL VALID):
  *   fused   0: a = loc, b = attn_w, ref unused      1: a = offsets, b = logits, ref as above
  *   variant 0: auto (tries 4, 3, 2, 1 in that order)
@@ -89,6 +100,8 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
  *           4: streaming quad kernel (same shapes; persistent workgroups + loader waves)
  *           5: streaming quad kernel with per-window flags instead of workgroup barriers
  *           6: streaming quad kernel walking the tiles of an image in raster order (4 and 5: 2-wide vertical strips)
+ *           7: streaming quad kernel with the earlier loader schedule (coarse window of tile k+1 requested under the
+ *              mid gather of tile k instead of behind its last barrier)
  *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that
  *           from their reference point take a slow path (results never depend on it).
  * Any other variant returns WM2F_EUNSUPPORTED: timing ablations and stamped builds live in the separate profiling

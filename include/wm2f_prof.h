@@ -21,9 +21,10 @@
 extern "C" {
 #endif
 
-/* Variants 73 / 74 of wm2f_msdeform_fwd_v stamp s_memtime of one gather wave and one loader wave (16 slots per
- * workgroup, first 8192 workgroups); this copies the stamps to HOST memory (int64 [8192][16], n_bytes <= 1 MiB).
- * Synchronous; no reference counterpart. */
+/* Variants 73 / 74 of wm2f_msdeform_fwd_v stamp s_memtime: 73 (phased kernel) wave 0 into slots 0-13 of its workgroup's
+ * row; 74 (streaming kernel, second tile of every workgroup) EVERY wave into [wave][slot] -- gather waves slots 0-9,
+ * loader waves slots 10-15.  This copies the stamps to HOST memory (int64 [8192 workgroups][160] = [8192][10 waves][16],
+ * n_bytes <= 10 MiB).  Synchronous; no reference counterpart. */
 int wm2f_debug_stamps(void* host_dst, int64_t n_bytes);
 
 #ifdef __cplusplus

@@ -172,6 +172,39 @@ def test_k1_fused_packed(ops, shapes, D):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shapes,B,spread", [([(8, 8), (16, 16), (32, 32)], 2, 2.0), ([(5, 7), (10, 14), (20, 28)], 3, 2.0),
+                                             ([(2, 3), (4, 6), (8, 12)], 1, 2.0), ([(9, 11), (18, 22), (36, 44)], 2, 9.0)])
+def test_k1_fused_lanes(ops, shapes, B, spread):
+    """The lane-major row order (wm2f_msdeform_fused_lanes_fwd): the same numbers as the [offsets | logits] rows, permuted
+    as include/wm2f.h says, give the same result as the oracle -- ragged tiles, and offsets far beyond the window margin
+    (spread 9: the slow path reads the lane-major rows too)."""
+    H, L, P, D = 8, 3, 4, 32
+    g = torch.Generator().manual_seed(13)
+    S = sum(h * w for h, w in shapes)
+    assert ops.k1_lanes_applies(shapes, S, D, P, B, H)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * spread
+    logits = torch.randn(B, S, H, L * P, generator=g) * 2
+    lanes = torch.empty(B, S, H, P, 9)
+    for l in range(L):
+        lanes[..., 2 * l] = off[:, :, :, l, :, 0]
+        lanes[..., 2 * l + 1] = off[:, :, :, l, :, 1]
+        lanes[..., 6 + l] = logits.view(B, S, H, L, P)[:, :, :, l, :]
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    ref = O.msdeform_attn_core(value, shapes, loc, torch.softmax(logits, -1).view(B, S, H, L, P))
+    out = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.reshape(B, S, H * 36)), H)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    # the other fused form on the same numbers: identical arithmetic, so identical bits
+    packed = torch.cat([off.reshape(B, S, -1), logits.reshape(B, S, -1)], -1)
+    out2 = ops.ms_deform_attn_fused_packed(dev(value), shapes, dev(packed), dev(ref_pts), H, L, P)
+    assert torch.equal(out, out2)
+    assert not ops.k1_lanes_applies([(5, 7), (10, 14), (20, 27)], 5 * 7 + 10 * 14 + 20 * 27, D, P, B, H)
+    with pytest.raises(Exception):  # a shape outside the streaming kernel is refused, not re-routed
+        ops.ms_deform_attn_fused_lanes(dev(value[:, :20 * 5]), [(2, 2), (4, 4), (8, 10)], dev(lanes.reshape(B, S, H * 36)[:, :100]), H)
+
+
 def test_k1_backward(ops):
     shapes = [(4, 6), (8, 12), (16, 24)]
     value, loc, w = _rand_k1(2, shapes, 8, 32, 3, spread=1.1)

@@ -17,6 +17,7 @@ NAMES = ["setup+operand loads issue", "DMA issue", "wait coarse(+operands)", "so
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", type=int, default=73)
+    ap.add_argument("--init", action="store_true", help="the module's initial offset pattern instead of uniform offsets in [-4, 4]")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B, H, D, L, P = 8, 8, 32, 3, 4
@@ -25,6 +26,12 @@ def main():
     torch.manual_seed(0)
     value = torch.randn(B, S, H, D, device=dev)
     off = torch.rand(B, S, H, L, P, 2, device=dev) * 8.0 - 4.0
+    if a.init:
+        th = torch.arange(H, device=dev, dtype=torch.float32) * (2.0 * 3.141592653589793 / H)
+        grid = torch.stack([th.cos(), th.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True)[0]
+        off = (grid[None, None, :, None, None, :] * torch.arange(1, P + 1, device=dev, dtype=torch.float32)[None, None, None, None, :, None]
+               ).expand(B, S, H, L, P, 2).contiguous()
     logits = torch.randn(B, S, H, L * P, device=dev)
     ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
                      for h, w in shapes]).to(dev)
@@ -33,21 +40,29 @@ def main():
         ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
     torch.cuda.synchronize()
     n_wg = B * H * 64 if a.variant == 73 else torch.cuda.get_device_properties(0).multi_processor_count
-    buf = np.zeros((min(n_wg, 8192), 16), dtype=np.int64)
+    buf = np.zeros((min(n_wg, 8192), 160), dtype=np.int64)
     check(load().wm2f_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "wm2f_debug_stamps")
-    if a.variant == 74:  # streaming kernel: second tile of every workgroup; slots 0-9 gather wave 0, 10-15 loader wave 8
+    if a.variant == 74:  # streaming kernel: second tile of every workgroup, every wave: [wg][wave][slot]
         g_names = ["coords/softmax", "Bc wait", "gather coarse", "Bm wait", "gather mid", "Bf wait", "fetch next operands",
                    "gather fine", "slow+stores"]
-        l_names = ["Bc wait", "issue fine", "wait mid + Bm wait", "issue coarse(next) + wait fine", "Bf wait"]
-        st = buf.astype(np.float64)
-        out = {"ticks": "s_memtime", "workgroups": int(st.shape[0])}
-        dg = np.diff(st[:, :10], axis=1)
-        for i, n in enumerate(g_names):
-            out["gather: " + n] = [float(np.percentile(dg[:, i], q)) for q in (10, 50, 90)]
-        out["gather: tile span"] = [float(np.percentile(st[:, 9] - st[:, 0], q)) for q in (10, 50, 90)]
-        dl = np.diff(st[:, 10:16], axis=1)
-        for i, n in enumerate(l_names):
-            out["loader: " + n] = [float(np.percentile(dl[:, i], q)) for q in (10, 50, 90)]
+        l_names = ["Bc wait", "issue fine A", "wait mid + Bm wait", "issue fine B + coarse(next) + wait fine", "Bf wait"]
+        st = buf.reshape(buf.shape[0], 10, 16).astype(np.float64)
+        pct = lambda x: [float(np.percentile(x, q)) for q in (10, 50, 90)]
+        out = {"ticks": "shader cycles (s_memtime)", "workgroups": int(st.shape[0]), "per_wave": {}}
+        for w in range(8):
+            dg = np.diff(st[:, w, :10], axis=1)
+            out["per_wave"][f"gather{w}"] = {n: pct(dg[:, i])[1] for i, n in enumerate(g_names)}
+            out["per_wave"][f"gather{w}"]["tile span"] = pct(st[:, w, 9] - st[:, w, 0])[1]
+        for w in (8, 9):
+            dl = np.diff(st[:, w, 10:16], axis=1)
+            out["per_wave"][f"loader{w - 8}"] = {n: pct(dl[:, i])[1] for i, n in enumerate(l_names)}
+        # who reaches each barrier last (wave index -> share of workgroups), and how long the first arrival waited
+        arrive = {"Bc": (1, 10), "Bm": (3, 12), "Bf": (5, 14)}  # (gather slot, loader slot) stamped just before the barrier
+        for name, (gs, ls) in arrive.items():
+            t = np.concatenate([st[:, :8, gs], st[:, 8:, ls]], axis=1)  # [wg][10]
+            last = t.argmax(1)
+            out[f"{name}: last arrival by wave"] = {int(w): round(float((last == w).mean()), 3) for w in range(10) if (last == w).any()}
+            out[f"{name}: first-to-last arrival spread"] = pct(t.max(1) - t.min(1))
         print(json.dumps(out, indent=1))
         return
     st = buf[:, :14].astype(np.float64)

@@ -80,6 +80,25 @@ def main():
                 r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=variant, margin=margin), a.iters)
                 r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
                 res[f"k1_fused_variant{variant}_margin{margin}"] = r
+        if "k1l" in only:  # fused forms: [offsets | logits] rows vs lane-major rows vs the round-1 loader schedule, interleaved rounds
+            packed = torch.cat([off.reshape(B, S, -1), logits.reshape(B, S, -1)], -1).contiguous()
+            lanes = torch.empty(B, S, H, P, 9, device=dev)
+            for l in range(L):
+                lanes[..., 2 * l] = off[:, :, :, l, :, 0]
+                lanes[..., 2 * l + 1] = off[:, :, :, l, :, 1]
+                lanes[..., 6 + l] = logits.view(B, S, H, L, P)[:, :, :, l, :]
+            lanes = lanes.reshape(B, S, H * 36).contiguous()
+            fns = {"packed_rows": lambda: ops.ms_deform_attn_fused_packed(value, shapes, packed, refl, H, L, P),
+                   "lane_major_rows": lambda: ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H),
+                   "two_arrays_sched1": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=4),
+                   "two_arrays_sched0": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=7)}
+            rounds = {k: [] for k in fns}
+            for _ in range(5):
+                for k_, fn in fns.items():
+                    rounds[k_].append(timeit(fn, a.iters)["med_us"])
+            for k_ in fns:
+                ts = sorted(rounds[k_])
+                res[f"k1_fused_{k_}"] = dict(min_us=ts[0], med_us=ts[len(ts) // 2], GBps=nbytes / ts[len(ts) // 2] / 1e3)
         if "k1o" in only:  # tile work order of the streaming kernel: 2-wide strips (4) against raster (6), interleaved rounds
             fns = {v: (lambda v=v: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=v, margin=4)) for v in (4, 6)}
             rounds = {v: [] for v in fns}

@@ -252,7 +252,7 @@ int launch_quad(const void* value, const void* a, const void* b, void* out, cons
 template <bool FUSED>
 int launch_stream(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
                   int Q, int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
-                  int b_qstride);
+                  int b_qstride, int lanes = 0);
 
 // msdeform_tiled_bwd.hip
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
@@ -281,6 +281,7 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
 //          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads;
 //          5 = streaming kernel with per-window flags instead of workgroup barriers
 //          6 = streaming kernel walking the tiles in raster order (default: 2-wide vertical strips)
+//          7 = streaming kernel with the round-1 loader schedule (coarse(k+1) requested under the mid gather of tile k)
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -295,16 +296,16 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   // the production library launches only kernels whose outputs are valid: 0 auto, 1 direct gather, 2 LDS windows,
   // 3 phased quads, 4 streaming quads, 5 streaming with flags, 6 streaming in raster tile order, 62 LDS windows in
   // slab-major order
-  if (!(variant >= 0 && variant <= 6) && variant != 62) {
+  if (!(variant >= 0 && variant <= 7) && variant != 62) {
     set_error("%s: variant %d is a timing ablation / stamped build: profiling library only (libwm2f_prof.so, "
               "include/wm2f_prof.h)", who, variant);
     return WM2F_EUNSUPPORTED;
   }
 #endif
-  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || variant == 5 || variant == 6)) {
+  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || (variant >= 5 && variant <= 7))) {
     bool handled = false;
     if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
-                                      variant == 5 ? 100 : (variant == 6 ? 200 : variant / 10), 0, 0))
+                                      variant == 5 ? 100 : (variant == 6 ? 200 : (variant == 7 ? 300 : variant / 10)), 0, 0))
       return rc;
     if (handled) return WM2F_OK;
     if (variant != 0) {
@@ -414,6 +415,29 @@ extern "C" int wm2f_msdeform_fused_packed_fwd(const void* value, const void* pac
   }
   if (!handled) {
     set_error("%s: needs D=32, P=4, Q==S, L<=4 and windows that fit LDS; use wm2f_msdeform_fused_fwd", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* out, const int32_t* level_hw,
+                                             int B, int S, int Q, int heads, int D, int L, int P, int dtype, void* stream) {
+  const char* who = "wm2f_msdeform_fused_lanes_fwd";
+  WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
+  WM2F_REQUIRE(value && lanes && out && level_hw, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && S > 0 && Q > 0 && heads > 0 && P > 0, "%s: non-positive size", who);
+  LevelInfo lv;
+  if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  bool handled = false;
+  if (D == 32 && L == 3 && P == 4) {
+    const int row = heads * L * P * 3;
+    if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, 0, row,
+                                     row, 1))
+      return rc;
+  }
+  if (!handled) {
+    set_error("%s: the lane-major form exists for the streaming kernel only (D = 32, P = 4, Q == S, 3 levels with sides "
+              "1:2:4 coarse first): use wm2f_msdeform_fused_packed_fwd with the [offsets | logits] rows", who);
     return WM2F_EUNSUPPORTED;
   }
   return WM2F_OK;

@@ -54,7 +54,7 @@ struct QuadGeom {
 // PROFILING build alone (libwm2f_prof.so, -DWM2F_PROFILING, include/wm2f_prof.h); the production library carries
 // MODE 0 kernels only and no global mutable state.
 #ifdef WM2F_PROFILING
-constexpr int kStampSlots = 16, kStampGroups = 8192;
+constexpr int kStampSlots = 160, kStampGroups = 8192;  // 10 waves x 16 slots per workgroup
 __device__ long long g_stamps[kStampGroups * kStampSlots];
 #define WM2F_STAMP(k)                                                                  \
   do {                                                                                 \
@@ -107,6 +107,7 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x4q = __attribute__((ext_vector_type(4))) float;
 
 struct Acc {
   f32x2 a_lo, a_hi, b_lo, b_hi;  // first-read half (4 channels), second-read half
@@ -560,9 +561,9 @@ static_assert(LWin<0>::n == 13 && LWin<1>::n == 21 && LWin<2>::n == 43, "vmcnt c
 // 10-15 by wave 8 (loader).
 #ifdef WM2F_PROFILING
 #define WM2F_SSTAMP(slot, who)                                                                              \
-  do {                                                                                                      \
-    if (MODE == 7 && k == 1 && tid == (who) * 64 && blockIdx.x < kStampGroups)                              \
-      g_stamps[blockIdx.x * kStampSlots + (slot)] = (long long)__builtin_readcyclecounter();                \
+  do { /* every wave of the role stamps its own row: [workgroup][wave][slot], second tile of the workgroup */ \
+    if (MODE == 7 && k == 1 && lane == 0 && blockIdx.x < kStampGroups)                                      \
+      g_stamps[blockIdx.x * kStampSlots + wave * 16 + (slot)] = (long long)__builtin_readcyclecounter();    \
   } while (0)
 #else
 #define WM2F_SSTAMP(slot, who) do { } while (0)
@@ -581,6 +582,8 @@ struct StreamGeom {
   // strip seams (3 per image instead of 7 tile-row seams) are fetched twice.
   int strip_w, full_strips, rem_w;
   float inv_per_strip, inv_strip_w, inv_rem_w;
+  int sched;   // loader schedule: 0 = coarse(k + 1) requested under the mid gather of tile k, 1 = behind Bf(k)
+  int lanes;   // operand layout of the fused form: 0 = [offsets | logits] per token, 1 = lane-major (see fetch)
 };
 
 // exact floor(a / d) for 0 <= a < 2^22 with inv ~ 1/d (one correction step either way)
@@ -842,6 +845,24 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       wg_barrier();    // Bm(k): gather waves are done with coarse(k)
       WM2F_SSTAMP(13, kLoaderWave0);
       loader_issue<2, kFA, LWin<2>::n>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      if (sg.sched == 1) {
+        // Per-wave stamps (profiles/r02_k1_stream_stamps_*.json): with coarse(k + 1) requested here the loaders were the
+        // last to reach Bf(k) in every workgroup, 1.5k cycles behind the gather waves.  The coarse window is not needed
+        // before Bc(k + 1), a whole fine gather away: request it behind Bf together with mid(k + 1).
+        wait_vm<0>();  // fine(k) landed
+        WM2F_SSTAMP(14, kLoaderWave0);
+        wg_barrier();  // Bf(k): gather waves are done with mid(k)
+        WM2F_SSTAMP(15, kLoaderWave0);
+        if (more) {
+          walk_step(walk, sg, heads);
+          lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
+          __builtin_amdgcn_sched_barrier(0);
+          loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+          __builtin_amdgcn_sched_barrier(0);
+          loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+        }
+        continue;
+      }
       if (more) {
         walk_step(walk, sg, heads);
         lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
@@ -950,10 +971,27 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       o.qrow[t2] = q;
       const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
       const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
+      if (FUSED && sg.lanes) {
+        // lane-major rows (wm2f_msdeform_fused_lanes_fwd): the 9 numbers of lane j of head h are consecutive --
+        // [x y] of its point on levels 0, 1, 2, then its three logits -- so a pass is 3 loads whose quad footprint is one
+        // 144-byte run, instead of 6 loads scattered over the token's 1152-byte row (16 quads x 6 loads x 8 waves queued
+        // in the texture-address unit behind the loaders' traffic: the per-wave stamps showed 3.0k cycles for the older and
+        // 5.5k for the younger wave of each SIMD in this fetch)
+        const int off = (int)__umul24((unsigned)q, (unsigned)a_row) + (t.h * 36 + j * 9) * 4;
+        const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
+        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, 0));
+        o.lc[t2][0] = make_float2(A.x, A.y);
+        o.lc[t2][1] = make_float2(A.z, A.w);
+        o.lc[t2][2] = make_float2(Bq.x, Bq.y);
+        o.wt[t2][0] = Bq.z;
+        o.wt[t2][1] = Bq.w;
+        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 32, 0, 0));
+      } else {
 #pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, 0));
-        o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, 0));
+        for (int l = 0; l < NL; ++l) {
+          o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, 0));
+          o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, 0));
+        }
       }
     }
     return o;
@@ -1046,15 +1084,20 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       if (wave_slow && cur.valid[t]) {
         unsigned todo = (unsigned)bcast<0>((int)slow[t]) | ((unsigned)bcast<1>((int)slow[t]) << 3) |
                         ((unsigned)bcast<2>((int)slow[t]) << 6) | ((unsigned)bcast<3>((int)slow[t]) << 9);
-        const float* ap = a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
-        const float* bp = b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
+        const bool lm = FUSED && sg.lanes;  // lane-major rows: point k2 of level l sits at [k2 * 9 + 2 * l], its logit at [k2 * 9 + 6 + l]
+        const float* ap = lm ? a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * 36
+                             : a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
+        const float* bp = lm ? ap : b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
+        auto logit_at = [&](int i) __attribute__((always_inline)) {  // i = l * P + k2
+          return lm ? bp[(i & 3) * 9 + 6 + (i >> 2)] : bp[i];
+        };
         float refx = 0.f, refy = 0.f, sm_max = 0.f, sm_inv = 1.f;
         if (FUSED && todo) {  // re-derive what the fast path no longer holds in registers
           ref_point(cur.qrow[t] - cur.b * Q, refx, refy);
-          sm_max = bp[0];
-          for (int i = 1; i < NL * P; ++i) sm_max = fmaxf(sm_max, bp[i]);
+          sm_max = logit_at(0);
+          for (int i = 1; i < NL * P; ++i) sm_max = fmaxf(sm_max, logit_at(i));
           float ssum = 0.f;
-          for (int i = 0; i < NL * P; ++i) ssum += __expf(bp[i] - sm_max);
+          for (int i = 0; i < NL * P; ++i) ssum += __expf(logit_at(i) - sm_max);
           sm_inv = __builtin_amdgcn_rcpf(ssum);
         }
         while (todo) {  // bit (k2 * 3 + l): point k2 of level l
@@ -1063,8 +1106,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
           const int k2 = i / 3, l = i - k2 * 3;
           const int Wl = g.W0 << l, Hl = g.H0 << l;
           const int st_l = l == 0 ? g.start[0] : (l == 1 ? g.start[1] : g.start[2]);
-          const float lx = ap[(l * P + k2) * 2], ly = ap[(l * P + k2) * 2 + 1];
-          float aw = bp[l * P + k2], x, y;
+          const float lx = lm ? ap[k2 * 9 + 2 * l] : ap[(l * P + k2) * 2], ly = lm ? ap[k2 * 9 + 2 * l + 1] : ap[(l * P + k2) * 2 + 1];
+          float aw = logit_at(l * P + k2), x, y;
           if (FUSED) {
             aw = __expf(aw - sm_max) * sm_inv;
             x = (refx * (float)Wl - 0.5f) + lx;
@@ -1146,7 +1189,7 @@ template int launch_quad<true>(const void*, const void*, const void*, void*, con
 template <bool FUSED>
 int launch_stream(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
                   int Q, int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
-                  int b_qstride) {
+                  int b_qstride, int lanes) {
   *handled = false;
   if (P != 4 || L != 3 || (int64_t)Q != S) return WM2F_OK;
   const int H0 = level_hw[0], W0 = level_hw[1];
@@ -1200,6 +1243,8 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_per_strip = sg.strip_w ? 1.f / (float)(sg.strip_w * g.tiles_y) : 0.f;
   sg.inv_strip_w = sg.strip_w ? 1.f / (float)sg.strip_w : 0.f;
   sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
+  sg.sched = (mode == 300) ? 0 : 1;  // mode 300: the round-1 loader schedule (A/B measurement)
+  sg.lanes = lanes;
   auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0>;
 #ifdef WM2F_PROFILING
   if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0>;
@@ -1219,9 +1264,9 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
 }
 
 template int launch_stream<false>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
-                                  int, void*, const char*, bool*, int, int, int);
+                                  int, void*, const char*, bool*, int, int, int, int);
 template int launch_stream<true>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
-                                 int, void*, const char*, bool*, int, int, int);
+                                 int, void*, const char*, bool*, int, int, int, int);
 
 }  // namespace wm2f
 

@@ -98,15 +98,29 @@ class MSDeformAttn(nn.Module):
         self.output_proj = nn.Linear(embed_dim, embed_dim)
         self._cat: dict = {}
 
-    def _offsets_logits_weight(self):
+    def _offsets_logits_weight(self, lanes: bool = False):
         """[sampling_offsets ; attention_weights] as ONE (288, 256) projection for the inference path:
-        two skinny GEMMs (N = 192 and N = 96, ~15 % of the fp32 matrix peak each) become one."""
+        two skinny GEMMs (N = 192 and N = 96, ~15 % of the fp32 matrix peak each) become one.
+        lanes=True: the same rows in the kernel's lane-major order (wm2f_msdeform_fused_lanes_fwd): per head and point
+        slot j, [x y of level 0, 1, 2 | logit of level 0, 1, 2] -- a row permutation of the weight, nothing else."""
         so, aw = self.sampling_offsets, self.attention_weights
         key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.device)
         if self._cat.get("key") != key:
             with torch.no_grad():
-                self._cat = dict(key=key, w=torch.cat([so.weight, aw.weight], 0).contiguous(),
-                                 b=torch.cat([so.bias, aw.bias], 0).contiguous())
+                w, b = torch.cat([so.weight, aw.weight], 0).contiguous(), torch.cat([so.bias, aw.bias], 0).contiguous()
+                self._cat = dict(key=key, w=w, b=b)
+                H, L, P = self.n_heads, self.n_levels, self.n_points
+                if L == 3 and P == 4:
+                    n_off = H * L * P * 2
+                    idx = torch.empty(H, P, 9, dtype=torch.int64)
+                    for l in range(L):
+                        for xy in range(2):  # offsets row ((h * L + l) * P + j) * 2 + xy
+                            idx[:, :, 2 * l + xy] = ((torch.arange(H)[:, None] * L + l) * P + torch.arange(P)[None, :]) * 2 + xy
+                        idx[:, :, 6 + l] = n_off + torch.arange(H)[:, None] * (L * P) + l * P + torch.arange(P)[None, :]  # logits row
+                    idx = idx.reshape(-1).to(w.device)
+                    self._cat.update(w_lanes=w[idx].contiguous(), b_lanes=b[idx].contiguous())
+        if lanes:
+            return self._cat["w_lanes"], self._cat["b_lanes"]
         return self._cat["w"], self._cat["b"]
 
     def forward(self, hidden, pos, ref, level_hw, hp=None):
@@ -123,6 +137,10 @@ class MSDeformAttn(nn.Module):
             loc = ref[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
             aw = torch.softmax(logits, -1).view(B, S, H, L, P)
             out = ops.ms_deform_attn(value, level_hw, loc, aw)
+        elif ops.k1_lanes_applies(level_hw, S, C // H, P, B, H) and hp.dtype == torch.float32:
+            # inference, the encoder's own shape: one merged projection with its rows in the kernel's lane order
+            w, b = self._offsets_logits_weight(lanes=True)
+            out = ops.ms_deform_attn_fused_lanes(value, level_hw, F.linear(hp, w, b), H)
         else:  # inference: one merged projection; softmax + location arithmetic fused into the kernel
             w, b = self._offsets_logits_weight()
             ol = F.linear(hp, w, b)  # (B, S, 288): [offsets (H*L*P*2) | logits (H*L*P)] per token

@@ -172,6 +172,37 @@ def ms_deform_attn_fused_packed(value, level_hw, packed, ref, heads: int, L: int
     return out
 
 
+def k1_lanes_applies(level_hw, n_tokens: int, head_dim: int, n_points: int, batch: int = 1, heads: int = 8) -> bool:
+    """Host-side copy of the shape test of wm2f_msdeform_fused_lanes_fwd (the streaming kernel): 3 levels with sides
+    exactly 1 : 2 : 4 coarse first, 4 points, head_dim 32, queries == tokens, 32-bit offsets."""
+    if len(level_hw) != 3 or n_points != 4 or head_dim != 32:
+        return False
+    (h0, w0), (h1, w1), (h2, w2) = [(int(a), int(b)) for a, b in level_hw]
+    if (h1, w1) != (2 * h0, 2 * w0) or (h2, w2) != (4 * h0, 4 * w0) or h0 < 1 or w0 < 1 or 21 * h0 * w0 != n_tokens:
+        return False
+    row = heads * 3 * 4 * 3 * 4
+    return batch * n_tokens < (1 << 24) and batch * n_tokens * row < 0x7fffffff and batch * n_tokens * heads * 128 < 0x7fffffff
+
+
+def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int):
+    """Inference K1 fed by ONE merged projection whose rows are in lane-major order (include/wm2f.h,
+    wm2f_msdeform_fused_lanes_fwd): lanes (B,Q,heads*36).  Streaming kernel only -- check `k1_lanes_applies` first; a
+    shape it does not take RAISES (no silent re-route: the caller owns the row order of its projection)."""
+    if torch.is_grad_enabled() and (value.requires_grad or lanes.requires_grad):
+        raise RuntimeError("ms_deform_attn_fused_lanes has no backward; use ms_deform_attn when training")
+    value, lanes = _req(_f32(value), "value"), _req(_f32(lanes), "lanes")
+    B, S, H, D = value.shape
+    Q = lanes.shape[1]
+    if H != heads or lanes.shape != (B, Q, heads * 36):
+        raise ValueError(f"ms_deform_attn_fused_lanes: value {tuple(value.shape)} lanes {tuple(lanes.shape)}")
+    out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
+    lv = host_i32([x for hw in level_hw for x in hw])
+    with torch.cuda.device(value.device):
+        check(_timed("msdeform_fused_fwd", value, lambda: load().wm2f_msdeform_fused_lanes_fwd(
+            _p(value), _p(lanes), _p(out), lv, B, S, Q, H, D, 3, 4, WM2F_F32, _stream(value))), "wm2f_msdeform_fused_lanes_fwd")
+    return out
+
+
 def ms_deform_attn_variant(value, level_hw, a, b, ref=None, fused=False, variant=0, margin=4) -> torch.Tensor:
     """K1 with the kernel variant exposed (no autograd): variant 0 auto, 1 direct gather, 2 LDS windows.
     fused=False: a = loc, b = attn_w.  fused=True: a = raw offsets, b = raw logits, ref (Q,L,2)."""
