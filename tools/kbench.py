@@ -45,7 +45,7 @@ def main():
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device="cpu").manual_seed(0)
     res = {}
-    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1s", "k1b")):
+    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1s", "k1b", "k1l", "k1o")):
         value = torch.randn(B, S, H, D, device=dev)
         # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
