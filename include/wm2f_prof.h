@@ -6,8 +6,9 @@
  *   - wm2f_msdeform_fwd_v accepts the timing ablations of K1, whose OUTPUTS ARE NOT VALID:
  *       12 / 22 / 32 / 42 / 52  LDS-window kernel: staging only, gather only, no operand loads, no LDS reads, neither
  *       13 / 23 / 43            phased quad kernel: staging only, gather only, no LDS reads
- *       44                      streaming quad kernel without LDS reads
- *       73 / 74                 phased / streaming quad kernel with in-kernel time stamps (valid outputs)
+ *       44                      streaming quad kernel (full-head form) without LDS reads
+ *       73 / 74 / 84            phased / full-head streaming / half-head streaming kernel with in-kernel time stamps
+ *                               (valid outputs)
  *   - K2 / K3 read their experiment knobs from the environment on every launch
  *       WM2F_K2_QTILES, WM2F_K2_WG_TARGET, WM2F_K2_FULL, WM2F_K2_QSPLIT, WM2F_K3_DBG   (tools/kbench.py)
  *   - the stamp buffer below: a __device__ global, i.e. the global mutable state the production library forbids.

@@ -39,29 +39,31 @@ def main():
     for _ in range(3):
         ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
     torch.cuda.synchronize()
-    n_wg = B * H * 64 if a.variant == 73 else torch.cuda.get_device_properties(0).multi_processor_count
+    n_wg = B * H * 64 if a.variant == 73 else torch.cuda.get_device_properties(0).multi_processor_count * (2 if a.variant == 84 else 1)
     buf = np.zeros((min(n_wg, 8192), 160), dtype=np.int64)
     check(load().wm2f_debug_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes), "wm2f_debug_stamps")
-    if a.variant == 74:  # streaming kernel: second tile of every workgroup, every wave: [wg][wave][slot]
+    if a.variant in (74, 84):  # streaming kernel: second tile of every workgroup, every wave: [wg][wave][slot]
         g_names = ["coords/softmax", "Bc wait", "gather coarse", "Bm wait", "gather mid", "Bf wait", "fetch next operands",
                    "gather fine", "slow+stores"]
         l_names = ["Bc wait", "issue fine A", "wait mid + Bm wait", "issue fine B + coarse(next) + wait fine", "Bf wait"]
         st = buf.reshape(buf.shape[0], 10, 16).astype(np.float64)
         pct = lambda x: [float(np.percentile(x, q)) for q in (10, 50, 90)]
         out = {"ticks": "shader cycles (s_memtime)", "workgroups": int(st.shape[0]), "per_wave": {}}
-        for w in range(8):
+        ngw = 7 if a.variant == 84 else 8  # half-head form: 7 gather waves + 1 loader; full-head: 8 + 2
+        loaders = [7] if a.variant == 84 else [8, 9]
+        for w in range(ngw):
             dg = np.diff(st[:, w, :10], axis=1)
             out["per_wave"][f"gather{w}"] = {n: pct(dg[:, i])[1] for i, n in enumerate(g_names)}
             out["per_wave"][f"gather{w}"]["tile span"] = pct(st[:, w, 9] - st[:, w, 0])[1]
-        for w in (8, 9):
+        for w in loaders:
             dl = np.diff(st[:, w, 10:16], axis=1)
-            out["per_wave"][f"loader{w - 8}"] = {n: pct(dl[:, i])[1] for i, n in enumerate(l_names)}
+            out["per_wave"][f"loader{w - ngw}"] = {n: pct(dl[:, i])[1] for i, n in enumerate(l_names)}
         # who reaches each barrier last (wave index -> share of workgroups), and how long the first arrival waited
         arrive = {"Bc": (1, 10), "Bm": (3, 12), "Bf": (5, 14)}  # (gather slot, loader slot) stamped just before the barrier
         for name, (gs, ls) in arrive.items():
-            t = np.concatenate([st[:, :8, gs], st[:, 8:, ls]], axis=1)  # [wg][10]
+            t = np.concatenate([st[:, :ngw, gs], st[:, loaders, ls]], axis=1)  # [wg][waves]
             last = t.argmax(1)
-            out[f"{name}: last arrival by wave"] = {int(w): round(float((last == w).mean()), 3) for w in range(10) if (last == w).any()}
+            out[f"{name}: last arrival by wave"] = {int(w): round(float((last == w).mean()), 3) for w in range(t.shape[1]) if (last == w).any()}
             out[f"{name}: first-to-last arrival spread"] = pct(t.max(1) - t.min(1))
         print(json.dumps(out, indent=1))
         return

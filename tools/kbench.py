@@ -90,8 +90,10 @@ def main():
             lanes = lanes.reshape(B, S, H * 36).contiguous()
             fns = {"packed_rows": lambda: ops.ms_deform_attn_fused_packed(value, shapes, packed, refl, H, L, P),
                    "lane_major_rows": lambda: ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H),
-                   "two_arrays_sched1": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=4),
-                   "two_arrays_sched0": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=7)}
+                   "two_arrays_half_head": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=4),
+                   "two_arrays_full_head": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=8),
+                   "two_arrays_half_head_sched0": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=7),
+                   "two_arrays_half_head_raster": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=6)}
             rounds = {k: [] for k in fns}
             for _ in range(5):
                 for k_, fn in fns.items():

@@ -282,6 +282,9 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
 //          5 = streaming kernel with per-window flags instead of workgroup barriers
 //          6 = streaming kernel walking the tiles in raster order (default: 2-wide vertical strips)
 //          7 = streaming kernel with the round-1 loader schedule (coarse(k+1) requested under the mid gather of tile k)
+//          8 = streaming kernel in its full-head form (one 149.5-KiB workgroup per CU; 4, 6, 7 are the half-head form:
+//              two 77-KiB workgroups per CU, each a 16-channel half of a head); 44 / 74 its ablation / stamped build,
+//              84 the stamped half-head build (profiling library)
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -294,18 +297,18 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
 #ifndef WM2F_PROFILING
   // the production library launches only kernels whose outputs are valid: 0 auto, 1 direct gather, 2 LDS windows,
-  // 3 phased quads, 4 streaming quads, 5 streaming with flags, 6 streaming in raster tile order, 62 LDS windows in
-  // slab-major order
-  if (!(variant >= 0 && variant <= 7) && variant != 62) {
+  // 3 phased quads, 4 streaming quads (half-head form), 5 full-head streaming with flags, 6 / 7 streaming in raster
+  // tile order / with the round-1 loader schedule, 8 full-head streaming, 62 LDS windows in slab-major order
+  if (!(variant >= 0 && variant <= 8) && variant != 62) {
     set_error("%s: variant %d is a timing ablation / stamped build: profiling library only (libwm2f_prof.so, "
               "include/wm2f_prof.h)", who, variant);
     return WM2F_EUNSUPPORTED;
   }
 #endif
-  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || (variant >= 5 && variant <= 7))) {
+  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 4 || (variant >= 5 && variant <= 8))) {
     bool handled = false;
-    if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
-                                      variant == 5 ? 100 : (variant == 6 ? 200 : (variant == 7 ? 300 : variant / 10)), 0, 0))
+    const int smode = variant == 5 ? 100 : variant == 6 ? 200 : variant == 7 ? 300 : variant == 8 ? 400 : variant == 84 ? 74 : variant / 10;
+    if (int rc = launch_stream<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, 0, 0))
       return rc;
     if (handled) return WM2F_OK;
     if (variant != 0) {

@@ -110,7 +110,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using f32x4q = __attribute__((ext_vector_type(4))) float;
 
 struct Acc {
-  f32x2 a_lo, a_hi, b_lo, b_hi;  // first-read half (4 channels), second-read half
+  f32x2 a_lo, a_hi, b_lo, b_hi;  // first-read half (4 channels), second-read half (unused when a lane owns 4 channels)
 };
 
 // Request one level's window: a wave-instruction moves 8 pixels x 128 B, lane-linear in LDS.
@@ -153,7 +153,8 @@ struct Prod {
 // `base`: 0, or the window's LDS byte address -- then the published address is absolute and a consumer needs one add
 // (its lane offset) per half instead of two (streaming kernel; the phased kernel keeps window-relative addresses
 // because its window reads must stay visibly based on the window's __shared__ array for the LDS-DMA tracking).
-template <int LV>
+// PB = bytes per window pixel: 128 (the head's 32 channels) or 64 (one 16-channel half).
+template <int LV, int PB = 128>
 __device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, int wy0, bool valid, unsigned& slow,
                                         int base = 0) {
   constexpr int WW = Win<LV>::side;
@@ -162,7 +163,7 @@ __device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, i
   const bool fast = ((unsigned)xr < (unsigned)(WW - 1)) & ((unsigned)yr < (unsigned)(WW - 1));
   const bool use = fast & valid;
   Prod p;
-  p.addr = base + (use ? (yr * WW + xr) * 128 : 0);
+  p.addr = base + (use ? (yr * WW + xr) * PB : 0);
   const float a = use ? aw : 0.f;
   slow |= (valid & !fast) ? (1u << LV) : 0u;
   const float fx1 = px - x0f, fy1 = py - y0f;
@@ -174,10 +175,10 @@ __device__ __forceinline__ Prod produce(float px, float py, float aw, int wx0, i
   return p;
 }
 
-// The corner reads of one point: 8 x 16 B (2 halves x 4 corners).  ONE such buffer rolls through a phase: as soon
-// as the FMA of corner i has issued, the read of the next point's corner i refills the same registers, so 7 to 8
-// reads stay in flight per wave at a cost of 32 registers (double-buffering whole points cost 72 and spilled in
-// the streaming kernel).
+// The corner reads of one point: 8 x 16 B (2 halves x 4 corners), or 4 x 16 B when a lane owns 4 channels.  ONE such
+// buffer rolls through a phase: as soon as the FMA of corner i has issued, the read of the next point's corner i refills
+// the same registers, so 7 to 8 reads stay in flight per wave at a cost of 32 registers (double-buffering whole points
+// cost 72 and spilled in the streaming kernel).
 struct Corners {
   float4 v[8];
 };
@@ -209,10 +210,10 @@ __device__ __forceinline__ PointAddr point_addr(const float4* win, const Prod& p
   return a;
 }
 
-template <int LV, int I, int MODE, bool ABS>
+template <int LV, int I, int MODE, bool ABS, int PB = 128>
 __device__ __forceinline__ float4 read_corner(const PointAddr& a) {
   constexpr int WW = Win<LV>::side;
-  constexpr int o = (I & 1) * 8 + ((I >> 1) & 1) * WW * 8;  // corner order: 00, 01, 10, 11
+  constexpr int o = (I & 1) * (PB / 16) + ((I >> 1) & 1) * WW * (PB / 16);  // corner order: 00, 01, 10, 11 (float4 units)
   if (MODE == 4) {  // ablation: no LDS reads
     if (ABS) asm volatile("" ::"v"(a.a1), "v"(a.a2));
     else asm volatile("" ::"v"(a.c1), "v"(a.c2));
@@ -226,18 +227,19 @@ __device__ __forceinline__ float4 read_corner(const PointAddr& a) {
 }
 
 // One level for all kPasses queries of the lane: 12 points (pass t, producer lane k), see Corners.
-template <int LV, int GI, int I, int MODE, bool ABS>
+// NC = corner reads per point and lane: 8 (a lane owns 8 channels: two 16-byte halves x 4 corners) or 4 (4 channels).
+template <int LV, int GI, int I, int MODE, bool ABS, int NC, int PB>
 __device__ __forceinline__ void corner_steps(Acc& acc, Corners& cr, const PointAddr& cur, const PointAddr& nxt) {
-  if constexpr (I < 8) {
+  if constexpr (I < NC) {
     if (I < 4) pk_fma4(acc.a_lo, acc.a_hi, cur.q[I & 3], cr.v[I]);
     else pk_fma4(acc.b_lo, acc.b_hi, cur.q[I & 3], cr.v[I]);
-    if constexpr (GI + 1 < kPasses * 4) cr.v[I] = read_corner<LV, I, MODE, ABS>(nxt);
+    if constexpr (GI + 1 < kPasses * 4) cr.v[I] = read_corner<LV, I, MODE, ABS, PB>(nxt);
     __builtin_amdgcn_sched_barrier(0);
-    corner_steps<LV, GI, I + 1, MODE, ABS>(acc, cr, cur, nxt);
+    corner_steps<LV, GI, I + 1, MODE, ABS, NC, PB>(acc, cr, cur, nxt);
   }
 }
 
-template <int LV, int GI, int MODE, bool ABS>
+template <int LV, int GI, int MODE, bool ABS, int NC, int PB>
 __device__ __forceinline__ void pipe_step(const float4* win, Acc (&acc)[kPasses], const Prod (&pr)[kPasses], int off1,
                                           int off2, Corners& cr, const PointAddr& cur, bool skip_last) {
   if constexpr (GI < kPasses * 4) {
@@ -245,37 +247,41 @@ __device__ __forceinline__ void pipe_step(const float4* win, Acc (&acc)[kPasses]
     PointAddr nxt = cur;
     if constexpr (GI + 1 < kPasses * 4) nxt = point_addr<LV, (GI + 1) & 3>(ABS ? nullptr : win, pr[(GI + 1) >> 2], off1, off2);
     __builtin_amdgcn_sched_barrier(0);
-    corner_steps<LV, GI, 0, MODE, ABS>(acc[GI >> 2], cr, cur, nxt);
+    corner_steps<LV, GI, 0, MODE, ABS, NC, PB>(acc[GI >> 2], cr, cur, nxt);
     // Pin the sums here: the accumulators are only stored at the very end, and LLVM's code sinking otherwise
     // moves whole FMA chains down there (every corner then stays live across all three phases: 500+ spills).
-    asm volatile("" : "+v"(acc[GI >> 2].a_lo), "+v"(acc[GI >> 2].a_hi), "+v"(acc[GI >> 2].b_lo), "+v"(acc[GI >> 2].b_hi));
-    pipe_step<LV, GI + 1, MODE, ABS>(win, acc, pr, off1, off2, cr, nxt, skip_last);
+    if (NC == 8) asm volatile("" : "+v"(acc[GI >> 2].a_lo), "+v"(acc[GI >> 2].a_hi), "+v"(acc[GI >> 2].b_lo), "+v"(acc[GI >> 2].b_hi));
+    else asm volatile("" : "+v"(acc[GI >> 2].a_lo), "+v"(acc[GI >> 2].a_hi));
+    pipe_step<LV, GI + 1, MODE, ABS, NC, PB>(win, acc, pr, off1, off2, cr, nxt, skip_last);
   }
 }
 
-template <int LV, int I, int MODE, bool ABS>
+template <int LV, int I, int MODE, bool ABS, int NC, int PB>
 __device__ __forceinline__ void first_reads(Corners& cr, const PointAddr& a) {
-  if constexpr (I < 8) {
-    cr.v[I] = read_corner<LV, I, MODE, ABS>(a);
-    first_reads<LV, I + 1, MODE, ABS>(cr, a);
+  if constexpr (I < NC) {
+    cr.v[I] = read_corner<LV, I, MODE, ABS, PB>(a);
+    first_reads<LV, I + 1, MODE, ABS, NC, PB>(cr, a);
   }
 }
 
-template <int LV, int MODE, bool ABS = false>
+// CH = channels per lane: 8 (a quad covers the head's 32 channels, 128-byte window pixels) or 4 (a quad covers one
+// 16-channel half of the head, 64-byte window pixels).
+template <int LV, int MODE, bool ABS = false, int CH = 8>
 __device__ __forceinline__ void gather_phase(const float4* win, Acc (&acc)[kPasses], const float (&px)[kPasses][3],
                                              const float (&py)[kPasses][3], const float (&wt)[kPasses][3],
                                              const bool (&valid)[kPasses], int wx0, int wy0, unsigned (&slow)[kPasses],
                                              int off1, int off2, bool skip_last) {
+  constexpr int NC = CH, PB = CH * 16;
   Prod pr[kPasses];
   const int base = ABS ? (int)(size_t)(lds_cf4_t)win : 0;
 #pragma unroll
   for (int t = 0; t < kPasses; ++t)
-    pr[t] = produce<LV>(px[t][LV], py[t][LV], wt[t][LV], wx0, wy0, valid[t], slow[t], base);
+    pr[t] = produce<LV, PB>(px[t][LV], py[t][LV], wt[t][LV], wx0, wy0, valid[t], slow[t], base);
   Corners cr;
   const PointAddr a0 = point_addr<LV, 0>(ABS ? nullptr : win, pr[0], off1, off2);
-  first_reads<LV, 0, MODE, ABS>(cr, a0);
+  first_reads<LV, 0, MODE, ABS, NC, PB>(cr, a0);
   __builtin_amdgcn_sched_barrier(0);
-  pipe_step<LV, 0, MODE, ABS>(win, acc, pr, off1, off2, cr, a0, skip_last);
+  pipe_step<LV, 0, MODE, ABS, NC, PB>(win, acc, pr, off1, off2, cr, a0, skip_last);
 }
 
 // Slow path for one point and 4 channels: per-corner image-bounds checks, corners from global memory.
@@ -551,11 +557,33 @@ __global__ __launch_bounds__(kThreads) void msdeform_quad_fwd_kernel(const float
 #define WM2F_STREAM_GATHER_WAVES 8
 #endif
 constexpr int kGatherWaves = WM2F_STREAM_GATHER_WAVES;  // 8 or 10 (10: 3 waves on every SIMD at the same 168 registers; measured 3 % slower)
-constexpr int kSThreads = (kGatherWaves + 2) * 64, kLoaderWave0 = kGatherWaves, kLoaders = 2;
+// Two forms of the streaming kernel, by the channels a gather lane owns (CH):
+//   CH = 8  a workgroup = (image, head, tile): 128-byte window pixels (149.5 KiB), 8 gather + 2 loader waves, ONE workgroup
+//           per CU.  Per-wave stamps (profiles/r02_k1_stream_stamps_*): the three gathers saturate the LDS for about half
+//           of a tile's 21k cycles; the other half (operand fetch through the texture-address unit, softmax /
+//           coordinates, stores, barrier skew behind the SIMD that carries two 3-pass waves) runs with the LDS idle --
+//           and nothing else is resident on the CU to use it.
+//   CH = 4  a workgroup = (image, head, 16-channel HALF, tile): 64-byte window pixels (77 KiB), 7 gather waves (7 x 16
+//           quads x 3 passes = the tile's 336 queries exactly: no wave idles in the third pass) + 1 loader wave, TWO
+//           workgroups per CU (128 registers per wave) that the hardware interleaves freely: one's gathers run under the
+//           other's fetch / coordinates / stores.  Same tiles, same windows, same halo; the price is that the two halves
+//           each fetch the operands and compute the coordinates of their queries.
+template <int CH> struct SCfg {
+  static_assert(CH == 8 || CH == 4, "channels per lane");
+  static constexpr int PB = CH * 16;         // bytes per window pixel
+  static constexpr int PPP = 1024 / PB;      // pixels per 1-KiB LDS-DMA piece
+  static constexpr int GW = CH == 8 ? kGatherWaves : 7, NLD = CH == 8 ? 2 : 1;
+  static constexpr int THREADS = (GW + NLD) * 64, SPLIT = 8 / CH;  // SPLIT = workgroups per (image, head, tile)
+};
+template <int LV, int CH> struct SWin {
+  static constexpr int chunks = (Win<LV>::npix + SCfg<CH>::PPP - 1) / SCfg<CH>::PPP;    // 25, 41, 85  /  13, 21, 43
+  static constexpr int n = (chunks + SCfg<CH>::NLD - 1) / SCfg<CH>::NLD;                // requests per loader
+};
 template <int LV> struct LWin {
-  static constexpr int n = (Win<LV>::chunks + kLoaders - 1) / kLoaders;  // requests per loader: 13, 21, 43
+  static constexpr int n = SWin<LV, 8>::n;  // requests per loader: 13, 21, 43 -- in BOTH forms (half the bytes, half the loaders)
 };
 static_assert(LWin<0>::n == 13 && LWin<1>::n == 21 && LWin<2>::n == 43, "vmcnt constants of the loader");
+static_assert(SWin<0, 4>::n == 13 && SWin<1, 4>::n == 21 && SWin<2, 4>::n == 43, "vmcnt constants of the loader, half-head form");
 
 // MODE 7 stamps of the streaming kernel: the workgroup's SECOND tile (steady state); slots 0-9 by wave 0 (gather),
 // 10-15 by wave 8 (loader).
@@ -596,7 +624,7 @@ __device__ __forceinline__ int div_small(int a, int d, float inv) {
 }
 
 struct TileId {
-  int b, h, tx, ty;
+  int b, h, tx, ty, hh;  // hh: which 16-channel half of the head (half-head form), else 0
 };
 
 // Position of a persistent workgroup in its tile sequence (all wave-uniform): image, head, and the tile's index within
@@ -626,10 +654,12 @@ __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int
     ++w.b;
   }
 }
-__device__ __forceinline__ TileId walk_tile(const TileWalk& w, const StreamGeom& sg) {
+// `split` = workgroups per (image, head, tile): the walk's innermost index is head * split + half
+__device__ __forceinline__ TileId walk_tile(const TileWalk& w, const StreamGeom& sg, int split = 1) {
   TileId t;
   t.b = w.b;
-  t.h = w.h;
+  t.h = split == 2 ? w.h >> 1 : w.h;
+  t.hh = split == 2 ? w.h & 1 : 0;
   if (sg.strip_w <= 0) {
     t.ty = div_small(w.tile, sg.q.tiles_x, sg.inv_tiles_x);
     t.tx = w.tile - t.ty * sg.q.tiles_x;
@@ -654,15 +684,16 @@ struct LoaderRegs {  // per-lane constants of one loader for one level
   unsigned rel[LWin<LV>::n];  // byte offset of this lane's 16 B relative to the window origin pixel
 };
 
-template <int LV>
+template <int LV, int CH>
 __device__ __forceinline__ void loader_init(LoaderRegs<LV>& r, int ld, int Wl, int row_bytes, unsigned pix_lane,
                                             unsigned lane_part) {
   using W = Win<LV>;
+  constexpr int kLoaders = SCfg<CH>::NLD, kChunks = SWin<LV, CH>::chunks, kPPP = SCfg<CH>::PPP;
 #pragma unroll
   for (int i = 0; i < LWin<LV>::n; ++i) {
     int c = ld + kLoaders * i;
-    c = c < W::chunks ? c : W::chunks - 1;
-    const unsigned idx = (unsigned)(c * 8) + pix_lane;
+    c = c < kChunks ? c : kChunks - 1;
+    const unsigned idx = (unsigned)(c * kPPP) + pix_lane;
     const unsigned wy = idx / (unsigned)W::side, wx = idx - wy * (unsigned)W::side;
     r.rel[i] = __umul24(__umul24(wy, (unsigned)Wl) + wx, (unsigned)row_bytes) + lane_part;
   }
@@ -672,16 +703,37 @@ __device__ __forceinline__ void loader_init(LoaderRegs<LV>& r, int ld, int Wl, i
 // slab (negative above / left of the image); x_border: the window sticks out left or right.
 typedef __attribute__((address_space(3))) float4* lds4_t;  // an LDS pointer that never passes through a generic one
 
-template <int LV, int I0, int I1>
+// The half-head form keeps only the fine window's table in registers (43 of the 77: its single loader wave lives under the
+// 128-register cap of two workgroups per CU) and recomputes the coarse / mid offsets per request (8 VALU each, 34 requests).
+template <int LV, int CH> constexpr bool kLoaderTable = (CH == 8) || (LV == 2);
+
+template <int LV, int I0, int I1, int CH>
 __device__ __forceinline__ void loader_issue(lds4_t win, const LoaderRegs<LV>& r, __amdgpu_buffer_rsrc_t slab, int ld,
-                                             int tile_off, bool x_border, int wx0, int Wl, unsigned pix_lane) {
+                                             int tile_off, bool x_border, int wx0, int Wl, unsigned pix_lane,
+                                             unsigned lane_part = 0, int row_bytes = 0) {
   using W = Win<LV>;
+  constexpr int kLoaders = SCfg<CH>::NLD, kChunks = SWin<LV, CH>::chunks, kPPP = SCfg<CH>::PPP;
   static_assert(I0 >= 0 && I1 <= LWin<LV>::n, "request range");
+  if constexpr (!kLoaderTable<LV, CH>) {
+    asm volatile("" : "+v"(pix_lane));  // keep the per-request arithmetic out of loop-invariant code motion (registers)
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      int c = ld + kLoaders * i;
+      c = c < kChunks ? c : kChunks - 1;
+      const unsigned idx = (unsigned)(c * kPPP) + pix_lane;
+      const unsigned wy = idx / (unsigned)W::side, wx = idx - wy * (unsigned)W::side;
+      const unsigned rel = __umul24(__umul24(wy, (unsigned)Wl) + wx, (unsigned)row_bytes) + lane_part;
+      const int x = wx0 + (int)wx;
+      const unsigned off = (!x_border || (unsigned)x < (unsigned)Wl) ? rel + (unsigned)tile_off : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, 0);
+    }
+    return;
+  }
   if (!x_border) {
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
       int c = ld + kLoaders * i;
-      c = c < W::chunks ? c : W::chunks - 1;
+      c = c < kChunks ? c : kChunks - 1;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)(r.rel[i] + (unsigned)tile_off), 0, 0, 0);
     }
   } else {
@@ -691,8 +743,8 @@ __device__ __forceinline__ void loader_issue(lds4_t win, const LoaderRegs<LV>& r
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
       int c = ld + kLoaders * i;
-      c = c < W::chunks ? c : W::chunks - 1;
-      const unsigned idx = (unsigned)(c * 8) + pix_lane;
+      c = c < kChunks ? c : kChunks - 1;
+      const unsigned idx = (unsigned)(c * kPPP) + pix_lane;
       const int x = wx0 + (int)(idx - (idx / (unsigned)W::side) * (unsigned)W::side);
       const unsigned off = ((unsigned)x < (unsigned)Wl) ? r.rel[i] + (unsigned)tile_off : kOobOffset;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, 0);
@@ -706,10 +758,11 @@ struct LoaderTile {  // wave-uniform per-tile values of the loaders
   bool x_border;
 };
 
-__device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, const TileId& t, int S, int heads) {
+__device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, const TileId& t, int S, int heads,
+                                                  int pixel_bytes = 128) {
   const QuadGeom& g = sg.q;
   const int row_stride = heads * 32, row_bytes = row_stride * 4, px0 = g.W0 * g.H0;
-  const float* vb = value + ((int64_t)t.b * S * heads + t.h) * 32;
+  const float* vb = value + ((int64_t)t.b * S * heads + t.h) * 32 + t.hh * 16;  // this head's slice (its second half: + 16 channels)
   LoaderTile lt;
   lt.x_border = false;
 #pragma unroll
@@ -721,7 +774,7 @@ __device__ __forceinline__ LoaderTile loader_tile(const float* value, const Stre
     lt.x_border = lt.x_border || wx0 < 0 || wx0 + Win<0>::side + (fq - (kQF >> 2)) > Wl;
     const int npx = px0 << (2 * l);
     lt.slab[l] = __builtin_amdgcn_make_buffer_rsrc((void*)(vb + (int64_t)g.start[l] * row_stride), 0,
-                                                   (npx - 1) * row_bytes + 32 * 4, 0x00020000);
+                                                   (npx - 1) * row_bytes + pixel_bytes, 0x00020000);
   }
   return lt;
 }
@@ -764,16 +817,16 @@ __device__ __forceinline__ void wave_done(int* p, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool FUSED, int MODE, int SYNC = 0>
-__global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const float* __restrict__ value,
-                                                                        const float* __restrict__ a_in,
-                                                                        const float* __restrict__ b_in,
-                                                                        float* __restrict__ out, StreamGeom sg, int S,
-                                                                        int Q, int heads) {
+template <bool FUSED, int MODE, int SYNC = 0, int CH = 8>
+__global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_stream_fwd_kernel(
+    const float* __restrict__ value, const float* __restrict__ a_in, const float* __restrict__ b_in, float* __restrict__ out,
+    StreamGeom sg, int S, int Q, int heads) {
   constexpr int D = 32, NL = 3, P = 4;
-  __shared__ __attribute__((aligned(16))) float4 win0[Win<0>::chunks * 64];
-  __shared__ __attribute__((aligned(16))) float4 win1[Win<1>::chunks * 64];
-  __shared__ __attribute__((aligned(16))) float4 win2[Win<2>::chunks * 64];
+  constexpr int kLoaderWave0 = SCfg<CH>::GW, kGW = SCfg<CH>::GW, kPB = SCfg<CH>::PB, kSplit = SCfg<CH>::SPLIT;
+  static_assert(SYNC == 0 || CH == 8, "the flag-synchronised form exists for the full-head kernel only");
+  __shared__ __attribute__((aligned(16))) float4 win0[SWin<0, CH>::chunks * 64];
+  __shared__ __attribute__((aligned(16))) float4 win1[SWin<1, CH>::chunks * 64];
+  __shared__ __attribute__((aligned(16))) float4 win2[SWin<2, CH>::chunks * 64];
   const QuadGeom& g = sg.q;
   // this workgroup's tiles: ids first + k * stride, k < n_my (XCD-contiguous ranges, as xcd_contiguous_id)
   const int xcd = blockIdx.x % kNumXcd, lw = blockIdx.x / kNumXcd;
@@ -792,13 +845,15 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
   if (wave >= kLoaderWave0) {
     // ------------------------------------------------------------------ loader waves
     const int ld = wave - kLoaderWave0;
-    const unsigned pix_lane = (unsigned)lane >> 3, lane_part = ((unsigned)lane & 7u) * 16u;
+    // a request moves 1 KiB = 8 pixels x 128 B or 16 pixels x 64 B, lane-linear in LDS
+    const unsigned pix_lane = CH == 8 ? (unsigned)lane >> 3 : (unsigned)lane >> 2;
+    const unsigned lane_part = CH == 8 ? ((unsigned)lane & 7u) * 16u : ((unsigned)lane & 3u) * 16u;
     LoaderRegs<0> r0;
     LoaderRegs<1> r1;
     LoaderRegs<2> r2;
-    loader_init<0>(r0, ld, g.W0, row_bytes, pix_lane, lane_part);
-    loader_init<1>(r1, ld, g.W0 << 1, row_bytes, pix_lane, lane_part);
-    loader_init<2>(r2, ld, g.W0 << 2, row_bytes, pix_lane, lane_part);
+    if (kLoaderTable<0, CH>) loader_init<0, CH>(r0, ld, g.W0, row_bytes, pix_lane, lane_part);
+    if (kLoaderTable<1, CH>) loader_init<1, CH>(r1, ld, g.W0 << 1, row_bytes, pix_lane, lane_part);
+    loader_init<2, CH>(r2, ld, g.W0 << 2, row_bytes, pix_lane, lane_part);
     // Schedule (per loader; F = fine window split in two parts so that no phase carries much more than a third of
     // a tile's requests -- the requests are accepted at the memory side's pace, ~100 cycles each per loader, and
     // the gather waves wait for the loader at every barrier):
@@ -806,29 +861,29 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     //   under the mid gather:               F(k) part B, coarse(k + 1)       (17 + 13)
     //   under the fine gather:              [pause: the gather waves fetch their next operands]  mid(k + 1)  (21)
     constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
-    TileWalk walk = walk_init(first, sg, heads);
-    LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
-    loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+    TileWalk walk = walk_init(first, sg, heads * kSplit);
+    LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
+    loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
     __builtin_amdgcn_sched_barrier(0);
-    loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+    loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
     if (SYNC == 1) {
       for (int k = 0; k < n_my; ++k) {
         wait_vm<LWin<1>::n>();  // coarse(k) landed
         publish(&ctrl[kCtrlReady + 0 * 2 + ld], k + 1, lane);
         wait_vm<0>();           // mid(k) landed
         publish(&ctrl[kCtrlReady + 1 * 2 + ld], k + 1, lane);
-        poll_ge(&ctrl[kCtrlDone + 2], kGatherWaves * k);  // every gather wave is done with fine(k - 1)
-        loader_issue<2, 0, LWin<2>::n>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+        poll_ge(&ctrl[kCtrlDone + 2], kGW * k);  // every gather wave is done with fine(k - 1)
+        loader_issue<2, 0, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
         wait_vm<0>();
         publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
         if (k + 1 < n_my) {
-          walk_step(walk, sg, heads);
-          lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
-          poll_ge(&ctrl[kCtrlDone + 0], kGatherWaves * (k + 1));
-          loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+          walk_step(walk, sg, heads * kSplit);
+          lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
+          poll_ge(&ctrl[kCtrlDone + 0], kGW * (k + 1));
+          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
           __builtin_amdgcn_sched_barrier(0);
-          poll_ge(&ctrl[kCtrlDone + 1], kGatherWaves * (k + 1));
-          loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+          poll_ge(&ctrl[kCtrlDone + 1], kGW * (k + 1));
+          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
         }
       }
       return;
@@ -839,12 +894,12 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       WM2F_SSTAMP(10, kLoaderWave0);
       wg_barrier();           // Bc(k): gather waves are done with fine(k-1)
       WM2F_SSTAMP(11, kLoaderWave0);
-      loader_issue<2, 0, kFA>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      loader_issue<2, 0, kFA, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
       WM2F_SSTAMP(12, kLoaderWave0);
       wait_vm<kFA>();  // mid(k) landed
       wg_barrier();    // Bm(k): gather waves are done with coarse(k)
       WM2F_SSTAMP(13, kLoaderWave0);
-      loader_issue<2, kFA, LWin<2>::n>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      loader_issue<2, kFA, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
       if (sg.sched == 1) {
         // Per-wave stamps (profiles/r02_k1_stream_stamps_*.json): with coarse(k + 1) requested here the loaders were the
         // last to reach Bf(k) in every workgroup, 1.5k cycles behind the gather waves.  The coarse window is not needed
@@ -854,20 +909,20 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
         wg_barrier();  // Bf(k): gather waves are done with mid(k)
         WM2F_SSTAMP(15, kLoaderWave0);
         if (more) {
-          walk_step(walk, sg, heads);
-          lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
+          walk_step(walk, sg, heads * kSplit);
+          lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           __builtin_amdgcn_sched_barrier(0);
-          loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
           __builtin_amdgcn_sched_barrier(0);
-          loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
         }
         continue;
       }
       if (more) {
-        walk_step(walk, sg, heads);
-        lt = loader_tile(value, sg, walk_tile(walk, sg), S, heads);
+        walk_step(walk, sg, heads * kSplit);
+        lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
         __builtin_amdgcn_sched_barrier(0);
-        loader_issue<0, 0, LWin<0>::n>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane);
+        loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
         wait_vm<LWin<0>::n>();  // fine(k) landed
       } else {
         wait_vm<0>();
@@ -877,7 +932,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
       WM2F_SSTAMP(15, kLoaderWave0);
       if (more) {
         __builtin_amdgcn_s_sleep(24);  // ~1.5k cycles: leave the memory path to the gather waves' operand loads
-        loader_issue<1, 0, LWin<1>::n>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane);
+        loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
       }
     }
     (void)kFB;
@@ -888,7 +943,11 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
   const int j = tid & 3, quad = lane >> 2;
   const int xq = (0x73261540 >> ((quad & 7) * 4)) & 7;  // bank-aware quad -> query order, see the kernel above
   const int slot = wave * 16 + (quad & 8) + xq;
-  const int hq = (quad >> 2) & 1;
+  // CH = 8: a lane owns 4 + 4 channels, the quad's two 64-byte halves of a 128-byte pixel (hq: which half first, for the
+  // banks).  CH = 4: a lane owns 4 channels, the quad covers the 64-byte pixel; the four quads of an LDS 16-lane group are
+  // x-neighbours (the xq order above), so for a slowly varying offset field they read four consecutive 64-byte pixels
+  // = all 64 banks once.
+  const int hq = CH == 8 ? (quad >> 2) & 1 : 0;
   const int off1 = j * 16 + hq * 64, off2 = j * 16 + (1 - hq) * 64;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_in, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_in, 0, 0x7fffffff, 0x00020000);
@@ -903,7 +962,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     float wt[kPasses][NL];
     int qrow[kPasses];  // b * Q + token
     bool valid[kPasses];
-    int wx0[NL], wy0[NL], b, h, tx, ty;
+    int wx0[NL], wy0[NL], b, h, tx, ty, hh;
   };
   // reference point of token q (HF:1127-1156): ((column + 0.5) / W_l, (row + 0.5) / H_l) of its own level (slow path only)
   auto ref_point = [&](int q, float& rx, float& ry) __attribute__((always_inline)) {
@@ -924,6 +983,7 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     o.h = t.h;
     o.tx = t.tx;
     o.ty = t.ty;
+    o.hh = t.hh;
     int nqx[NL], nqy[NL], qfirst[NL], key = 0;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -945,8 +1005,9 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
         // the loaders share their SIMDs with waves (0, 4) and (1, 5) (waves go to SIMDs cyclically), so waves 4
         // and 5 -- and 6, whose SIMD then carries 3 + 2 passes -- stay at two passes
         // With 10 gather waves two passes cover 320 queries and wave 2 takes the last 16.
-        const int w3 = kGatherWaves == 8 ? (wave < 4 ? wave : (wave == 7 ? 4 : 1 << 20)) : (wave == 2 ? 0 : 1 << 20);
-        int qi = t2 < 2 ? slot + (kGatherWaves * 16) * t2 : 2 * (kGatherWaves * 16) + w3 * 16 + (quad & 8) + xq;
+        // Half-head form: 7 gather waves x 16 quads x 3 passes = 336 = a full tile's queries: every wave takes three passes.
+        const int w3 = kGW == 7 ? wave : (kGW == 8 ? (wave < 4 ? wave : (wave == 7 ? 4 : 1 << 20)) : (wave == 2 ? 0 : 1 << 20));
+        int qi = t2 < 2 ? slot + (kGW * 16) * t2 : 2 * (kGW * 16) + w3 * 16 + (quad & 8) + xq;
         pc.valid[t2] = qi < nq;
         if (!pc.valid[t2]) qi = 0;  // an empty slot shadows the tile's first query (a real token: loads stay in range)
         const bool ge1 = qi >= c1, ge2 = qi >= c2;
@@ -997,8 +1058,8 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     return o;
   };
 
-  TileWalk walk = walk_init(first, sg, heads);
-  Ops nxt = fetch(walk_tile(walk, sg));
+  TileWalk walk = walk_init(first, sg, heads * kSplit);
+  Ops nxt = fetch(walk_tile(walk, sg, kSplit));
   for (int k = 0; k < n_my; ++k) {
     Ops cur = nxt;
     WM2F_SSTAMP(0, 0);
@@ -1054,28 +1115,36 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
     WM2F_SSTAMP(1, 0);
     window_ready(0);  // Bc(k)
     WM2F_SSTAMP(2, 0);
-    gather_phase<0, MODE, true>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
+    gather_phase<0, MODE, true, CH>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
     if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 0], lane);
     WM2F_SSTAMP(3, 0);
     window_ready(1);  // Bm(k)
     WM2F_SSTAMP(4, 0);
-    gather_phase<1, MODE, true>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
+    gather_phase<1, MODE, true, CH>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
     if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 1], lane);
     WM2F_SSTAMP(5, 0);
     window_ready(2);  // Bf(k)
     WM2F_SSTAMP(6, 0);
-    if (k + 1 < n_my) {  // lands under the fine gather
-      walk_step(walk, sg, heads);
-      nxt = fetch(walk_tile(walk, sg));
+    if (CH == 8 && k + 1 < n_my) {  // lands under the fine gather
+      walk_step(walk, sg, heads * kSplit);
+      nxt = fetch(walk_tile(walk, sg, kSplit));
     }
     __builtin_amdgcn_sched_barrier(0);
     WM2F_SSTAMP(7, 0);
-    gather_phase<2, MODE, true>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
+    gather_phase<2, MODE, true, CH>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
     if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 2], lane);
     WM2F_SSTAMP(8, 0);
+    if (CH == 4 && k + 1 < n_my) {
+      // half-head form: 128 registers per wave leave no room to hold the next tile's 27 operand registers through the
+      // fine gather; they are requested here and land under the stores, the loop turn and the other workgroup's work
+      __builtin_amdgcn_sched_barrier(0);
+      walk_step(walk, sg, heads * kSplit);
+      nxt = fetch(walk_tile(walk, sg, kSplit));
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- slow points (rare), then the stores
-    const float* vb = value + ((int64_t)cur.b * S * heads + cur.h) * D;
+    const float* vb = value + ((int64_t)cur.b * S * heads + cur.h) * D + cur.hh * 16;
     const bool wave_slow = __builtin_amdgcn_ballot_w64((slow[0] | slow[1] | slow[2]) != 0) != 0;
 #pragma unroll
     for (int t = 0; t < kPasses; ++t) {
@@ -1118,12 +1187,12 @@ __global__ __launch_bounds__(kSThreads) void msdeform_stream_fwd_kernel(const fl
           }
           const float* vlev = vb + (int64_t)st_l * row_stride;
           quad_point_slow(r1, vlev + (off1 >> 2), Hl, Wl, row_stride, x, y, aw);
-          quad_point_slow(r2, vlev + (off2 >> 2), Hl, Wl, row_stride, x, y, aw);
+          if (CH == 8) quad_point_slow(r2, vlev + (off2 >> 2), Hl, Wl, row_stride, x, y, aw);
         }
       }
-      const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4)) : kOobOffset;
+      const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4) + cur.hh * 64) : kOobOffset;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, 0);
+      if (CH == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, 0);
     }
     WM2F_SSTAMP(9, 0);
   }
@@ -1190,6 +1259,11 @@ template <bool FUSED>
 int launch_stream(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
                   int Q, int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
                   int b_qstride, int lanes) {
+  // mode: 0 the kernel that runs (half-head form); 400 the full-head form (one workgroup per CU: the round-1 kernel);
+  //       100 full-head with flags instead of barriers; 200 / 300 half-head in raster tile order / with the round-1 loader
+  //       schedule; 4 / 7 (profiling build) full-head without LDS reads / stamped; 74 half-head stamped
+  const bool half = !(mode == 400 || mode == 100 || mode == 4 || mode == 7);
+  const int split = half ? 2 : 1;
   *handled = false;
   if (P != 4 || L != 3 || (int64_t)Q != S) return WM2F_OK;
   const int H0 = level_hw[0], W0 = level_hw[1];
@@ -1207,7 +1281,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   g.start[2] = 5 * H0 * W0;
   g.a_qstride = a_qstride > 0 ? a_qstride : heads * L * P * 2;
   g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
-  const int64_t n_logical = (int64_t)B * heads * g.tiles_x * g.tiles_y;
+  const int64_t n_logical = (int64_t)B * heads * split * g.tiles_x * g.tiles_y;
   const int64_t lim = 0x7fffffff;
   if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || g.b_qstride * 4 >= (1 << 24) ||
       (int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
@@ -1224,18 +1298,18 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
     }
     n_cu = prop.multiProcessorCount;
   }
-  int wg = n_cu - n_cu % kNumXcd;  // a multiple of the XCD count
+  int wg = (n_cu - n_cu % kNumXcd) * split;  // a multiple of the XCD count; the half-head form keeps two workgroups per CU
   if (wg < kNumXcd) wg = kNumXcd;
   sg.n_logical = (int)n_logical;
   sg.per_xcd = (int)ceil_div64(n_logical, kNumXcd);
   sg.wg_per_xcd = wg / kNumXcd;
   if (sg.wg_per_xcd > sg.per_xcd) sg.wg_per_xcd = sg.per_xcd;
   wg = sg.wg_per_xcd * kNumXcd;
-  sg.inv_heads = 1.f / (float)heads;
+  sg.inv_heads = 1.f / (float)(heads * split);
   sg.inv_ntiles = 1.f / (float)(g.tiles_x * g.tiles_y);
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
-  sg.step_t = sg.wg_per_xcd / heads;
-  sg.step_h = sg.wg_per_xcd % heads;
+  sg.step_t = sg.wg_per_xcd / (heads * split);
+  sg.step_h = sg.wg_per_xcd % (heads * split);
   // tile work order inside an image: 2-wide vertical strips (see StreamGeom); mode 200 = plain raster (A/B measurement)
   sg.strip_w = (mode == 200 || g.tiles_x < 2) ? 0 : 2;
   sg.full_strips = sg.strip_w ? g.tiles_x / sg.strip_w : 0;
@@ -1245,14 +1319,20 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
   sg.sched = (mode == 300) ? 0 : 1;  // mode 300: the round-1 loader schedule (A/B measurement)
   sg.lanes = lanes;
-  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0>;
+  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 4>;
+  int threads = SCfg<4>::THREADS;
+  if (!half) {
+    kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8>;
+    threads = SCfg<8>::THREADS;
+  }
 #ifdef WM2F_PROFILING
-  if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0>;
-  if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0>;
+  if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8>;
+  if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8>;
+  if (mode == 74) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 4>;
 #endif
-  if (mode == 100) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1>;  // flags instead of barriers
-  // (mode 200: the same kernel as mode 0, raster tile order -- set above)
-  hipLaunchKernelGGL(kfn, dim3(wg), dim3(kSThreads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
+  if (mode == 100) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8>;  // flags instead of barriers
+  // (modes 200 / 300: the half-head kernel in raster tile order / with the round-1 loader schedule -- set above)
+  hipLaunchKernelGGL(kfn, dim3(wg), dim3(threads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
