@@ -97,11 +97,11 @@ int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* ou
  *           1: direct gather (any D)
  *           2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4);  62: the same in slab-major work order
  *           3: phased quad kernel (3 levels with sides 1:2:4 coarse first, P = 4, D = 32, margin 4)
- *           4: streaming quad kernel (same shapes; persistent workgroups + loader waves), half-head form: a workgroup
- *              gathers one 16-channel half of a head, two workgroups share a CU
- *           8: streaming quad kernel, full-head form (one workgroup per CU: the round-1 kernel)
- *           5: full-head streaming kernel with per-window flags instead of workgroup barriers
- *           6: streaming quad kernel walking the tiles of an image in raster order (4 and 5: 2-wide vertical strips)
+ *           4: streaming quad kernel (same shapes; persistent workgroups + loader waves), one workgroup per CU
+ *           8: the same in its half-head form: a workgroup gathers one 16-channel half of a head, two workgroups
+ *              share a CU (measured slower: twice the L2 requests)
+ *           5: streaming kernel with per-window flags instead of workgroup barriers
+ *           6: streaming quad kernel walking the tiles of an image in 2-wide vertical strips (4, 5: raster order)
  *           7: streaming quad kernel with the earlier loader schedule (coarse window of tile k+1 requested under the
  *              mid gather of tile k instead of behind its last barrier)
  *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that

@@ -45,7 +45,7 @@ def main():
     S = sum(h * w for h, w in shapes)
     g = torch.Generator(device="cpu").manual_seed(0)
     res = {}
-    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1s", "k1b", "k1l", "k1o")):
+    if any(k in only for k in ("k1", "k1f", "k1v", "k1t", "k1q", "k1s", "k1b", "k1l", "k1o", "k1h")):
         value = torch.randn(B, S, H, D, device=dev)
         # reference points + the module's initial offset pattern (|offset| <= 4 px) + noise
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
@@ -90,10 +90,10 @@ def main():
             lanes = lanes.reshape(B, S, H * 36).contiguous()
             fns = {"packed_rows": lambda: ops.ms_deform_attn_fused_packed(value, shapes, packed, refl, H, L, P),
                    "lane_major_rows": lambda: ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H),
-                   "two_arrays_half_head": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=4),
-                   "two_arrays_full_head": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=8),
-                   "two_arrays_half_head_sched0": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=7),
-                   "two_arrays_half_head_raster": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=6)}
+                   "two_arrays": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=4),
+                   "two_arrays_half_head": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=8),
+                   "two_arrays_sched0": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=7),
+                   "two_arrays_strips": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=6)}
             rounds = {k: [] for k in fns}
             for _ in range(5):
                 for k_, fn in fns.items():
@@ -102,7 +102,7 @@ def main():
                 ts = sorted(rounds[k_])
                 res[f"k1_fused_{k_}"] = dict(min_us=ts[0], med_us=ts[len(ts) // 2], GBps=nbytes / ts[len(ts) // 2] / 1e3)
         if "k1o" in only:  # tile work order of the streaming kernel: 2-wide strips (4) against raster (6), interleaved rounds
-            fns = {v: (lambda v=v: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=v, margin=4)) for v in (4, 6)}
+            fns = {v: (lambda v=v: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=v, margin=4)) for v in (4, 6)}  # 4 raster, 6 strips
             rounds = {v: [] for v in fns}
             for _ in range(5):
                 for v, fn in fns.items():
@@ -118,8 +118,8 @@ def main():
                 o.backward(go)
                 vv.grad = ll.grad = ww_.grad = None
             res["k1_fwd_plus_bwd"] = timeit(fb, a.iters)
-        if "k1t" in only or "k1q" in only or "k1s" in only:  # one variant only, for PMC runs (LDS-window / phased quad / streaming)
-            vv_ = 2 if "k1t" in only else (3 if "k1q" in only else 4)
+        if any(k in only for k in ("k1t", "k1q", "k1s", "k1h")):  # one variant only, for PMC runs (LDS-window / phased quad / streaming half-head / full-head)
+            vv_ = 2 if "k1t" in only else (3 if "k1q" in only else (8 if "k1h" in only else 4))  # k1h: half-head form
             r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=vv_, margin=4), a.iters)
             r.update(bytes=nbytes, GBps=nbytes / r["med_us"] / 1e3)
             res[f"k1_fused_variant{vv_}_margin4"] = r

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: tools/pmc.sh <tag> <kbench --only value> ; runs several rocprofv3 --pmc passes on tools/kbench.py
+# usage: tools/pmc.sh <tag> <kbench --only value> [extra kbench flags, e.g. --init] ; runs several rocprofv3 --pmc passes on tools/kbench.py
 # (counters in their own runs: no tracing options beside --pmc)
 set -e
-TAG=$1; ONLY=$2
+TAG=$1; ONLY=$2; EXTRA=$3
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -12,7 +12,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr" \
            "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --only $ONLY --iters 3 > $O/p$i.log 2>&1
+  timeout -k 10 150 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --only $ONLY --iters 3 $EXTRA > $O/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

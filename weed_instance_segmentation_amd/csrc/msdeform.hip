@@ -280,10 +280,10 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
 //          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations;
 //          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads;
 //          5 = streaming kernel with per-window flags instead of workgroup barriers
-//          6 = streaming kernel walking the tiles in raster order (default: 2-wide vertical strips)
+//          6 = streaming kernel walking the tiles in 2-wide vertical strips (default: raster)
 //          7 = streaming kernel with the round-1 loader schedule (coarse(k+1) requested under the mid gather of tile k)
-//          8 = streaming kernel in its full-head form (one 149.5-KiB workgroup per CU; 4, 6, 7 are the half-head form:
-//              two 77-KiB workgroups per CU, each a 16-channel half of a head); 44 / 74 its ablation / stamped build,
+//          8 = streaming kernel in its half-head form (two 77-KiB workgroups per CU, each a 16-channel half of a head;
+//              measured slower than the full-head form 4); 44 / 74 ablation / stamped build of the full-head form,
 //              84 the stamped half-head build (profiling library)
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
@@ -297,8 +297,8 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
 #ifndef WM2F_PROFILING
   // the production library launches only kernels whose outputs are valid: 0 auto, 1 direct gather, 2 LDS windows,
-  // 3 phased quads, 4 streaming quads (half-head form), 5 full-head streaming with flags, 6 / 7 streaming in raster
-  // tile order / with the round-1 loader schedule, 8 full-head streaming, 62 LDS windows in slab-major order
+  // 3 phased quads, 4 streaming quads, 5 streaming with flags, 6 / 7 streaming in strip tile order / with the round-1
+  // loader schedule, 8 half-head streaming, 62 LDS windows in slab-major order
   if (!(variant >= 0 && variant <= 8) && variant != 62) {
     set_error("%s: variant %d is a timing ablation / stamped build: profiling library only (libwm2f_prof.so, "
               "include/wm2f_prof.h)", who, variant);

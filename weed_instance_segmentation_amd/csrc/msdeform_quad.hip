@@ -568,6 +568,12 @@ constexpr int kGatherWaves = WM2F_STREAM_GATHER_WAVES;  // 8 or 10 (10: 3 waves 
 //           workgroups per CU (128 registers per wave) that the hardware interleaves freely: one's gathers run under the
 //           other's fetch / coordinates / stores.  Same tiles, same windows, same halo; the price is that the two halves
 //           each fetch the operands and compute the coordinates of their queries.
+//           MEASURED (profiles/r02_pmc_k1_half_vs_full.txt, r02_kbench_k1_half_head.jsonl): 18 % SLOWER than CH = 8
+//           (214-220 us against 184 us on the same box).  Every window request now asks L2 for 64-byte half lines:
+//           TCP->TCC read requests 16.5 M against 8.2 M per launch, texture-address unit busy 72 % of the kernel against
+//           55 %, L2 misses + 24 %, VALU instructions + 21 % -- the request path, not the LDS, is what a second workgroup
+//           per CU runs into.  Kept selectable (wm2f_msdeform_fwd_v variant 8) as the measured negative; variant 4 / the
+//           production entry points run CH = 8.
 template <int CH> struct SCfg {
   static_assert(CH == 8 || CH == 4, "channels per lane");
   static constexpr int PB = CH * 16;         // bytes per window pixel
@@ -607,7 +613,8 @@ struct StreamGeom {
   // An XCD holds 32 workgroups = 4 tiles x 8 heads at a time and its L2 (4 MiB) about three tiles' windows, so in
   // raster order the 10 halo rows a tile row shares with the next one are long gone when that row comes round
   // (2 x 8 x 1.2 MB later); in 2-wide strips the row below follows 2 tiles later and finds them in L2, and only the
-  // strip seams (3 per image instead of 7 tile-row seams) are fetched twice.
+  // strip seams (3 per image instead of 7 tile-row seams) are fetched twice.  Measured (profiles/r02_kbench_k1_tile_order):
+  // no faster than raster (165 vs 169 us), so raster stays the default.
   int strip_w, full_strips, rem_w;
   float inv_per_strip, inv_strip_w, inv_rem_w;
   int sched;   // loader schedule: 0 = coarse(k + 1) requested under the mid gather of tile k, 1 = behind Bf(k)
@@ -1259,10 +1266,11 @@ template <bool FUSED>
 int launch_stream(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S,
                   int Q, int heads, int L, int P, void* stream, const char* who, bool* handled, int mode, int a_qstride,
                   int b_qstride, int lanes) {
-  // mode: 0 the kernel that runs (half-head form); 400 the full-head form (one workgroup per CU: the round-1 kernel);
-  //       100 full-head with flags instead of barriers; 200 / 300 half-head in raster tile order / with the round-1 loader
-  //       schedule; 4 / 7 (profiling build) full-head without LDS reads / stamped; 74 half-head stamped
-  const bool half = !(mode == 400 || mode == 100 || mode == 4 || mode == 7);
+  // mode: 0 the kernel that runs: full-head form (one workgroup per CU), raster tile order, coarse(k + 1) requested behind Bf;
+  //       400 the half-head form (two workgroups per CU; measured SLOWER: see SCfg); 100 flags instead of barriers;
+  //       200 tiles in 2-wide vertical strips; 300 the round-1 loader schedule;
+  //       4 / 7 (profiling build) without LDS reads / stamped; 74 half-head stamped
+  const bool half = (mode == 400 || mode == 74);
   const int split = half ? 2 : 1;
   *handled = false;
   if (P != 4 || L != 3 || (int64_t)Q != S) return WM2F_OK;
@@ -1310,8 +1318,9 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
   sg.step_t = sg.wg_per_xcd / (heads * split);
   sg.step_h = sg.wg_per_xcd % (heads * split);
-  // tile work order inside an image: 2-wide vertical strips (see StreamGeom); mode 200 = plain raster (A/B measurement)
-  sg.strip_w = (mode == 200 || g.tiles_x < 2) ? 0 : 2;
+  // tile work order inside an image: plain raster; mode 200 = 2-wide vertical strips (see StreamGeom; A/B measurement:
+  // 169 against 165 us -- the seams a strip order saves were not what the kernel waits for)
+  sg.strip_w = (mode == 200 && g.tiles_x >= 2) ? 2 : 0;
   sg.full_strips = sg.strip_w ? g.tiles_x / sg.strip_w : 0;
   sg.rem_w = sg.strip_w ? g.tiles_x - sg.full_strips * sg.strip_w : 0;
   sg.inv_per_strip = sg.strip_w ? 1.f / (float)(sg.strip_w * g.tiles_y) : 0.f;
