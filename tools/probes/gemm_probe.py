@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""What the library (hipBLASLt through torch) makes of the token GEMMs of the pixel decoder / transformer decoder at config 2:
+out (M, N) = x (M, K) @ W (N, K)^T + bias, fp32.  TFLOP/s per shape against the 157.3 TFLOP/s fp32 matrix peak."""
+import json
+import sys
+import torch
+import torch.nn.functional as F
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+shapes = [("value_proj / output_proj", 172032, 256, 256), ("offsets+logits merged", 172032, 256, 288), ("fc1 (+ReLU)", 172032, 256, 1024),
+          ("fc2", 172032, 1024, 256), ("decoder K/V fine", 131072, 256, 256), ("decoder K/V mid", 32768, 256, 256),
+          ("decoder K/V coarse", 8192, 256, 256)]
+for name, M, K, N in shapes:
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.05
+    b = torch.randn(N, device=dev)
+    us = timeit(lambda: F.linear(x, w, b))
+    flop = 2.0 * M * K * N
+    print(json.dumps({"gemm": name, "M": M, "K": K, "N": N, "us": round(us, 1), "TFLOPs": round(flop / us / 1e6, 1),
+                      "frac_of_157.3": round(flop / us / 1e6 / 157.3, 3)}))

@@ -8,9 +8,13 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [r for r in rows if "attn_mask_build" in r["Kernel_Name"]]  # 10 per forward, the last closes a step
-t0, t1 = int(marks[-11]["End_Timestamp"]), int(marks[-1]["End_Timestamp"])
-sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1]
+marks = [r for r in rows if "resize_pyramid" in r["Kernel_Name"]]  # one per forward (the level-resolution mask route)
+if len(marks) >= 2:
+    t0, t1 = int(marks[-2]["Start_Timestamp"]), int(marks[-1]["Start_Timestamp"])
+else:  # no pyramid launch in the trace: every prediction at full resolution -- 10 mask builds per forward close a step
+    marks = [r for r in rows if "attn_mask_build" in r["Kernel_Name"]]
+    t0, t1 = int(marks[-10]["End_Timestamp"]), int(marks[-1]["End_Timestamp"])
+sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0 and int(r["Start_Timestamp"]) < t1]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in sel:
     agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
