@@ -222,6 +222,16 @@ int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y
 int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,
                        const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
                        int64_t pos_rows, float eps, void* stream);
+/* wm2f_token_linear_fwd: out (M, N) = epilogue(x (M, K) . W (N, K)^T + bias[N]) on the fp32 matrix cores, for the narrow Linears
+ *                        of the pixel decoder's encoder layers (HF:978 value_proj, :983-991 sampling_offsets | attention_weights
+ *                        merged, :1012 output_proj, :1086 fc2).  N = 256 or 288, K % 64 == 0, all fp32 row-major (W as
+ *                        nn.Linear stores it).  Epilogue, in this order:  relu != 0: max(., 0);  ln_gamma / ln_beta != NULL:
+ *                        LayerNorm over the N features of (value + residual[M, N]) (residual may be NULL) -- HF:1076-1078,
+ *                        :1086-1088;  out_plus_pos != NULL: additionally out + pos[row % pos_rows] (the next layer's
+ *                        `hidden + pos`, HF:972).  x / out below 2 GiB each. */
+int wm2f_token_linear_fwd(const void* x, const void* w, const void* bias, const void* residual, const void* ln_gamma,
+                          const void* ln_beta, const void* pos, void* out, void* out_plus_pos, int64_t M, int K, int N, int relu,
+                          int64_t pos_rows, float eps, void* stream);
 /* wm2f_tokens_to_nchw: out (B, C, HW) = tokens (B, S, C) rows [start, start + HW) transposed per image -- the
  *                      `hidden[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` of HF:1384-1391. */
 int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int start, int HW, void* stream);

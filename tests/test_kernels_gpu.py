@@ -633,3 +633,45 @@ def test_resize_pyramid_equals_three_bilinear_resizes(ops, N, C, H, W):
         torch.testing.assert_close(y.cpu(), ref, rtol=1e-5, atol=1e-6)
     with pytest.raises(ValueError):
         ops.resize_pyramid(dev(torch.zeros(1, 1, 12, 16)))
+
+
+@pytest.mark.parametrize("M,K,N,relu,ln,res,pos", [(700, 256, 256, False, False, False, False), (4096 + 37, 256, 288, False, False, False, False),
+                                                   (1000, 256, 256, False, True, True, False), (2 * 336, 1024, 256, False, True, True, True),
+                                                   (16, 64, 256, True, False, False, False), (5, 128, 288, True, True, False, False),
+                                                   (172032 // 8, 256, 256, False, True, True, True)])
+def test_token_linear_fused_epilogues(ops, M, K, N, relu, ln, res, pos):
+    """wm2f_token_linear_fwd (fp32 MFMA token GEMM with bias / ReLU / residual + LayerNorm / + pos fused) against the same
+    chain of stock torch ops in fp64 on the CPU; exact-integer operands pin the fragment layout; ragged token counts (not a
+    multiple of 16, fewer tokens than waves) exercise the tile split."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    gamma, beta = (torch.randn(N, generator=g), torch.randn(N, generator=g)) if ln else (None, None)
+    rows = M // 2 if (pos and M % 2 == 0) else M
+    pe = torch.randn(rows, N, generator=g) if pos else None
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if relu:
+        ref = ref.relu()
+    if ln:
+        if res:
+            ref = ref + r.double()
+        ref = torch.nn.functional.layer_norm(ref, (N,), gamma.double(), beta.double(), 1e-5)
+    out = ops.token_linear(dev(x), dev(w), dev(b), relu=relu, residual=dev(r) if res else None,
+                           ln=(dev(gamma), dev(beta), 1e-5) if ln else None, pos=dev(pe) if pos else None)
+    out_pos = None
+    if pos:
+        out, out_pos = out
+    scale = ref.abs().max().item()
+    assert (out.cpu().double() - ref).abs().max().item() <= 3e-6 * scale * math.sqrt(K)
+    if pos:
+        refp = ref + pe.double().repeat(M // rows, 1)
+        assert (out_pos.cpu().double() - refp).abs().max().item() <= 3e-6 * refp.abs().max().item() * math.sqrt(K)
+    assert ops.token_linear_applies(dev(x), dev(w))
+    if not ln:
+        xi = torch.randint(-3, 4, (M, K), generator=g).float()
+        wi = torch.randint(-3, 4, (N, K), generator=g).float()
+        bi = torch.randint(-5, 6, (N,), generator=g).float()
+        exp = torch.nn.functional.linear(xi, wi, bi)
+        assert torch.equal(ops.token_linear(dev(xi), dev(wi), dev(bi), relu=relu).cpu(), exp.relu() if relu else exp)

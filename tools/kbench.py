@@ -167,6 +167,27 @@ def main():
             logits = ops.mask_einsum(emb, pix)
             for hw in shapes:
                 res[f"attn_mask_build_{hw[0]}"] = timeit(lambda: ops.attn_mask_build(logits, hw), a.iters)
+    if "tg" in only:  # token GEMMs of the encoder layers: wm2f_token_linear_fwd against the library (F.linear) + the separate LayerNorm pass
+        import torch.nn.functional as F
+        Mtok = B * S
+        for name, K, N, ln in (("value_proj", 256, 256, False), ("offsets_logits", 256, 288, False), ("output_proj+ln", 256, 256, True),
+                               ("fc2+ln+pos", 1024, 256, True)):
+            x = torch.randn(Mtok, K, device=dev)
+            w = torch.randn(N, K, device=dev) * 0.05
+            bb = torch.randn(N, device=dev)
+            res_ = torch.randn(Mtok, N, device=dev) if ln else None
+            gm, bt = torch.randn(N, device=dev), torch.randn(N, device=dev)
+            pe = torch.randn(S, N, device=dev) if "pos" in name else None
+            flop = 2.0 * Mtok * K * N
+            r = timeit(lambda: ops.token_linear(x, w, bb, residual=res_, ln=(gm, bt, 1e-5) if ln else None, pos=pe), a.iters)
+            r.update(TFLOPs=flop / r["med_us"] / 1e6)
+            res[f"token_linear_{name}"] = r
+            if ln:
+                r = timeit(lambda: ops.add_layernorm(F.linear(x, w, bb), res_, gm, bt, 1e-5, pos=pe), a.iters)
+            else:
+                r = timeit(lambda: F.linear(x, w, bb), a.iters)
+            r.update(TFLOPs=flop / r["med_us"] / 1e6)
+            res[f"library_{name}"] = r
     if "k3m" in only:  # K3 with the fused attention-mask epilogue at the three level resolutions (the inference route)
         emb = torch.randn(B, Q, 256, device=dev)
         for hw in shapes:

@@ -34,3 +34,20 @@ for name, M, K, N in shapes:
     flop = 2.0 * M * K * N
     print(json.dumps({"gemm": name, "M": M, "K": K, "N": N, "us": round(us, 1), "TFLOPs": round(flop / us / 1e6, 1),
                       "frac_of_157.3": round(flop / us / 1e6 / 157.3, 3)}))
+
+# does the library do better on the same GEMM cut into row chunks? (172 032 rows = 131 072 + 40 960, = 2 x 86 016, = 3 x 57 344)
+print("--- row chunking of the 172 032-token GEMMs")
+for name, K, N in (("value/output_proj", 256, 256), ("offsets+logits", 256, 288)):
+    M = 172032
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.05
+    b = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    for cuts in ([M], [131072, 40960], [86016, 86016], [57344] * 3, [65536, 65536, 40960], [43008] * 4):
+        def run():
+            o = 0
+            for c in cuts:
+                torch.addmm(b, x[o:o + c], w.t(), out=out[o:o + c])
+                o += c
+        us = timeit(run)
+        print(json.dumps({"gemm": name, "cuts": cuts, "us": round(us, 1), "TFLOPs": round(2.0 * M * K * N / us / 1e6, 1)}))

@@ -62,6 +62,11 @@ class Mask2FormerForUniversalSegmentationOutput:
 
 
 _POS_CACHE: dict = {}
+# Route the narrow token Linears of the pixel decoder's encoder layers (value_proj, merged offsets | logits, output_proj +
+# residual + LayerNorm) through csrc/token_gemm.hip instead of the library GEMM + the separate LayerNorm pass.  Off by
+# default: measured at config 2 the hand-written kernel is at parity with hipBLASLt on these shapes, not ahead
+# (DESIGN.md 4.9); WM2F_TOKEN_GEMM=1 turns it on for A/B runs.
+TOKEN_GEMM = os.environ.get("WM2F_TOKEN_GEMM", "0") == "1"
 
 
 def sine_position_embedding(H: int, W: int, num_pos_feats: int, device, dtype=torch.float32, temperature=10000):
@@ -123,13 +128,19 @@ class MSDeformAttn(nn.Module):
             return self._cat["w_lanes"], self._cat["b_lanes"]
         return self._cat["w"], self._cat["b"]
 
-    def forward(self, hidden, pos, ref, level_hw, hp=None):
-        """hidden (B,S,C); pos (S,C) shared by the batch; ref (S,L,2); hp = hidden + pos if already known."""
+    def forward(self, hidden, pos, ref, level_hw, hp=None, fuse_ln=None):
+        """hidden (B,S,C); pos (S,C) shared by the batch; ref (S,L,2); hp = hidden + pos if already known.
+        fuse_ln = (residual, LayerNorm): return LayerNorm(output_proj(.) + residual) from the token-GEMM epilogue."""
         B, S, C = hidden.shape
         H, L, P = self.n_heads, self.n_levels, self.n_points
         if hp is None:
             hp = hidden + pos[None]
-        value = self.value_proj(hidden).view(B, S, H, C // H)
+        tg = (TOKEN_GEMM and not torch.is_grad_enabled() and ops.token_linear_applies(hidden, self.value_proj.weight)
+              and not torch.is_autocast_enabled("cuda"))
+        if tg:  # the narrow token GEMMs on the hand-written fp32 MFMA kernel (csrc/token_gemm.hip)
+            value = ops.token_linear(hidden, self.value_proj.weight, self.value_proj.bias).view(B, S, H, C // H)
+        else:
+            value = self.value_proj(hidden).view(B, S, H, C // H)
         if torch.is_grad_enabled() and (hidden.requires_grad or self.value_proj.weight.requires_grad):
             off = self.sampling_offsets(hp).view(B, S, H, L, P, 2)
             logits = self.attention_weights(hp).view(B, S, H, L * P)
@@ -140,11 +151,15 @@ class MSDeformAttn(nn.Module):
         elif ops.k1_lanes_applies(level_hw, S, C // H, P, B, H) and hp.dtype == torch.float32:
             # inference, the encoder's own shape: one merged projection with its rows in the kernel's lane order
             w, b = self._offsets_logits_weight(lanes=True)
-            out = ops.ms_deform_attn_fused_lanes(value, level_hw, F.linear(hp, w, b), H)
+            rows = ops.token_linear(hp, w, b) if tg and ops.token_linear_applies(hp, w) else F.linear(hp, w, b)
+            out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H)
         else:  # inference: one merged projection; softmax + location arithmetic fused into the kernel
             w, b = self._offsets_logits_weight()
             ol = F.linear(hp, w, b)  # (B, S, 288): [offsets (H*L*P*2) | logits (H*L*P)] per token
             out = ops.ms_deform_attn_fused_packed(value, level_hw, ol, ref, H, L, P)
+        if fuse_ln is not None:  # (residual, LayerNorm module): output_proj + residual + LayerNorm in one kernel (HF:1012, :1076-1078)
+            res, ln = fuse_ln
+            return ops.token_linear(out, self.output_proj.weight, self.output_proj.bias, residual=res, ln=(ln.weight, ln.bias, ln.eps))
         return self.output_proj(out)
 
 
@@ -168,9 +183,12 @@ class PixelDecoderEncoderLayer(nn.Module):
             # inference: residual + LayerNorm fused (and the next layer's hidden + pos with the second one);
             # bias + ReLU in the fc1 GEMM epilogue
             B_, S_, C_ = hidden.shape
-            a = self.self_attn(hidden, pos, ref, level_hw, hp)
             ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
-            hidden = ops.add_layernorm(a, hidden, ln1.weight, ln1.bias, ln1.eps)
+            if TOKEN_GEMM and ops.token_linear_applies(hidden, self.self_attn.output_proj.weight):
+                hidden = self.self_attn(hidden, pos, ref, level_hw, hp, fuse_ln=(hidden, ln1))
+            else:
+                a = self.self_attn(hidden, pos, ref, level_hw, hp)
+                hidden = ops.add_layernorm(a, hidden, ln1.weight, ln1.bias, ln1.eps)
             f = torch._addmm_activation(self.fc1.bias, hidden.reshape(B_ * S_, C_), self.fc1.weight.t(), use_gelu=False)
             f = self.fc2(f).view(B_, S_, C_)
             return ops.add_layernorm(f, hidden, ln2.weight, ln2.bias, ln2.eps, pos=pos)

@@ -530,6 +530,47 @@ def add_layernorm(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None
     return (out, out_pos) if pos is not None else out
 
 
+def token_linear_applies(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes wm2f_token_linear_fwd is built for: fp32 on a GPU, N in {256, 288}, K a multiple of 64, x / out below 2 GiB."""
+    N, K = weight.shape
+    M = x.numel() // max(K, 1)
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and N in (256, 288) and K % 64 == 0
+            and x.shape[-1] == K and M * K * 4 < (1 << 31) and M * N * 4 < (1 << 31))
+
+
+def token_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool = False, residual: torch.Tensor | None = None,
+                 ln: tuple | None = None, pos: torch.Tensor | None = None):
+    """Linear over tokens with its epilogue fused (inference, no autograd): x (..., K) @ weight (N, K)^T + bias, then
+    optional ReLU, optional LayerNorm(value + residual) with ln = (gamma, beta, eps), and with `pos` (rows_per_image, N)
+    additionally out + pos broadcast over the batch.  Returns out, or (out, out + pos)."""
+    x, weight, bias = _req(x, "x"), _req(weight, "weight"), _req(bias, "bias")
+    N, K = weight.shape
+    if x.shape[-1] != K or bias.shape != (N,):
+        raise ValueError(f"token_linear: x {tuple(x.shape)} weight {tuple(weight.shape)} bias {tuple(bias.shape)}")
+    M = x.numel() // K
+    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    gamma = beta = None
+    eps = 0.0
+    if ln is not None:
+        gamma, beta, eps = _req(ln[0], "gamma"), _req(ln[1], "beta"), float(ln[2])
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if residual.numel() != M * N:
+            raise ValueError("token_linear: residual shape")
+    out_pos, pos_rows = None, 0
+    if pos is not None:
+        pos = _req(pos, "pos")
+        pos_rows = pos.numel() // N
+        if M % pos_rows:
+            raise ValueError("token_linear: pos rows do not divide the token count")
+        out_pos = torch.empty_like(out)
+    with torch.cuda.device(x.device):
+        check(_timed(f"token_linear_K{K}_N{N}" + ("_ln" if ln is not None else ""), x, lambda: load().wm2f_token_linear_fwd(
+            _p(x), _p(weight), _p(bias), _p(residual), _p(gamma), _p(beta), _p(pos), _p(out), _p(out_pos), M, K, N, 1 if relu else 0,
+            pos_rows, eps, _stream(x))), "wm2f_token_linear_fwd")
+    return (out, out_pos) if pos is not None else out
+
+
 def tokens_to_nchw(tokens: torch.Tensor, start: int, h: int, w: int) -> torch.Tensor:
     """tokens (B, S, C) rows [start, start + h*w) -> (B, C, h, w), tiled transpose (inference only, no autograd)."""
     tokens = _req(tokens, "tokens")
