@@ -28,6 +28,17 @@
 //     loaded by exactly one wave, one super-step ahead of its use.
 // Roofline: fp32 MFMA, 2 M N K flop against 157.3 TFLOP/s.  HBM side: x once, out once (+ residual, + pos): 0.35-0.53 GB
 // per call, far from binding.
+//
+// Where it stands (one MI355X, config-2 shapes, tools/kbench.py --only tg; profiles/r02_kbench_token_gemm.jsonl): 260 us for
+// the 256 -> 256 projections (86.6 TFLOP/s, the library: 262 us), 280 us for the merged 288-wide one (library 292), 339 us
+// with the residual + LayerNorm epilogue (library GEMM + the separate LayerNorm pass: 311), 992 us for fc2 + LayerNorm + pos
+// (library 842: its K = 1024 kernel runs at 80 % of the peak).  Parity, not a win -- so the model keeps the library GEMMs by
+// default (WM2F_TOKEN_GEMM=1 switches).  Timing ablations of the profiling build (WM2F_TG_MODE, outputs not valid): without
+// the epilogue's loads and stores 231 us, without x loads 255, without LDS reads 261, without barriers 260, with none of
+// them 219 -- against 151 us of pure MFMA issue at the 2.38 GHz the chip holds under this load (tools/probes/mfma_clock.hip
+// measures 154.6 TFLOP/s for the same instruction mix on register operands): the epilogue (all waves of all CUs store at
+// the same moments, the turns being in lock-step) and the turn structure around the MFMA stream are what is left, not the
+// operand paths.  Next: stagger the waves' turns by a phase each so that one wave's epilogue runs under the others' MFMAs.
 #include "common.h"
 #include <stdlib.h>
 
@@ -60,11 +71,11 @@ __device__ __forceinline__ void tg_barrier() {
 }
 
 // NRT = N / 16 row tiles (16: N = 256, 18: N = 288); CT = column tiles (16 tokens each) a wave works on per turn
-// MODE (profiling build only; outputs NOT valid): 1 = no x loads (B operand from registers), 2 = no LDS reads of W
-// (A operand from registers), 3 = neither, 4 = no barriers (the panels are read while they land)
+// MODE bits (profiling build only; outputs NOT valid): 1 = no x loads (B operand from registers), 2 = no LDS reads of W
+// (A operand from registers), 4 = no barriers (the panels are read while they land), 8 = no epilogue loads / stores
 template <int NRT, int CT, int MODE = 0>
 __global__ __launch_bounds__(kTgThreads) void token_gemm_kernel(TgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float panels[];  // [2][NRT][4][64][4]
+  extern __shared__ __attribute__((aligned(16))) float panels[];  // [2][NRT][4][64][4], then bias | gamma | beta (N floats each)
   constexpr int kPanelFloats = NRT * 4 * 64 * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_cu = gridDim.x, cu = blockIdx.x;
@@ -76,6 +87,15 @@ __global__ __launch_bounds__(kTgThreads) void token_gemm_kernel(TgArgs a) {
   const int share_max = (n_t + kTgWaves - 1) / kTgWaves;
   const int n_iter = (share_max + CT - 1) / CT;
   const int n_q = n_iter * n_phase;  // panel phases of this workgroup
+  float* vec = panels + 2 * kPanelFloats;  // the epilogue's per-feature vectors: read from LDS (lgkmcnt), so that no load of
+                                           // them sits in the vmcnt queue between the stores (the compiler answered that
+                                           // with vmcnt(0) per row tile: store, wait, load, wait, ...)
+  for (int i = tid; i < 3 * NRT * 16; i += kTgThreads) {
+    const int which = i / (NRT * 16), f = i - which * (NRT * 16);
+    const float* srcv = which == 0 ? a.bias : (which == 1 ? a.gamma : a.beta);
+    vec[i] = srcv ? srcv[f] : 0.f;
+  }
+  __syncthreads();
   if (n_q == 0) return;
 
   if (wave == kTgWaves) {
@@ -173,6 +193,15 @@ __global__ __launch_bounds__(kTgThreads) void token_gemm_kernel(TgArgs a) {
           else dst[u] = *reinterpret_cast<const f32x4*>(panel + (((r2 + u) * 4 + s) * 64 + lane) * 4);
         }
       };
+      if (!live[0]) {
+        // a wave whose share is used up still meets every barrier, but issues no MFMA on its empty tile (the matrix pipe
+        // is its SIMD partner's); its B ring keeps turning so that the load count per phase stays the same
+        load_b(bq[3], xo_cur, kk + 48);
+        load_b(bq[0], xs, k_next);
+        load_b(bq[1], xs, k_next + 16);
+        load_b(bq[2], xs, k_next + 32);
+        continue;
+      }
       read_a(av[0], 0);
 #pragma unroll
       for (int G = 0; G < kGroups; ++G) {
@@ -200,23 +229,44 @@ __global__ __launch_bounds__(kTgThreads) void token_gemm_kernel(TgArgs a) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       if (!live[c]) continue;  // wave-uniform
+      if (MODE & 8) {  // ablation: no epilogue traffic (one store keeps the sums alive)
+        f32x4 v = acc[0][c];
+#pragma unroll
+        for (int rt = 1; rt < NRT; ++rt) v += acc[rt][c];
+        if (v[0] == 12345.f) a.out[0] = v[1] + v[2] + v[3];
+        continue;
+      }
       const int64_t tk = tok[c];
       const bool tok_ok = tk < a.M;
       const unsigned row_o = tok_ok ? (unsigned)(tk * a.N * 4) : kOob;
-      float s1 = 0.f, s2 = 0.f;
+      constexpr int NF = NRT * 16;
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt) {
-        const int f0 = rt * 16 + 4 * g;
-        f32x4 v = acc[rt][c] + *reinterpret_cast<const f32x4*>(a.bias + f0);
+        f32x4 v = acc[rt][c] + *reinterpret_cast<const f32x4*>(vec + rt * 16 + 4 * g);
         if (a.relu) v = __builtin_elementwise_max(v, (f32x4){0.f, 0.f, 0.f, 0.f});
-        if (a.gamma) {
-          if (a.residual && tok_ok) v += *reinterpret_cast<const f32x4*>(a.residual + tk * a.N + f0);
-          s1 += (v[0] + v[1]) + (v[2] + v[3]);
-          s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
         acc[rt][c] = v;
       }
       if (a.gamma) {  // LayerNorm over the token's N features: this lane's NRT * 4 values, then the 4 lane groups
+        constexpr int kEB = NRT % 4 == 0 ? 4 : 3;  // row tiles per batch of epilogue loads (16 / 12 registers: the kernel sits at its 168-register cap)
+        if (a.residual) {  // loads in batches; the accumulators hold the sums
+          const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.residual, 0, (int)(a.M * a.N * 4), 0x00020000);
+#pragma unroll
+          for (int h0 = 0; h0 < NRT; h0 += kEB) {
+            f32x4 rv[kEB];
+#pragma unroll
+            for (int i = 0; i < kEB; ++i)
+              rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, row_o + (unsigned)(((h0 + i) * 16 + 4 * g) * 4), 0, 0));
+#pragma unroll
+            for (int i = 0; i < kEB; ++i) acc[h0 + i][c] += rv[i];
+          }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          const f32x4 v = acc[rt][c];
+          s1 += (v[0] + v[1]) + (v[2] + v[3]);
+          s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
         s1 += __shfl_xor(s1, 16, 64);
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 16, 64);
@@ -226,16 +276,29 @@ __global__ __launch_bounds__(kTgThreads) void token_gemm_kernel(TgArgs a) {
         float var = s2 * inv_n - mean * mean;
         var = var < 0.f ? 0.f : var;
         const float rstd = rsqrtf(var + a.eps);
-        const float* prow = (a.out_pos && tok_ok) ? a.pos + (tk % a.pos_rows) * a.N : nullptr;
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
           const int f0 = rt * 16 + 4 * g;
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + f0), bt = *reinterpret_cast<const f32x4*>(a.beta + f0);
-          const f32x4 v = (acc[rt][c] - mean) * rstd * gm + bt;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rs, row_o + (unsigned)(f0 * 4), 0, 0);
-          if (prow) {
-            const f32x4 vp = v + *reinterpret_cast<const f32x4*>(prow + f0);
-            *reinterpret_cast<f32x4*>(a.out_pos + tk * a.N + f0) = vp;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(vec + NF + f0), bt = *reinterpret_cast<const f32x4*>(vec + 2 * NF + f0);
+          acc[rt][c] = (acc[rt][c] - mean) * rstd * gm + bt;
+        }
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[rt][c]), o_rs, row_o + (unsigned)((rt * 16 + 4 * g) * 4), 0, 0);
+        if (a.out_pos) {  // the next layer's hidden + pos: pos rows in two batches, then the stores
+          const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.pos, 0, (int)(a.pos_rows * a.N * 4), 0x00020000);
+          const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out_pos, 0, (int)(a.M * a.N * 4), 0x00020000);
+          const unsigned prow = tok_ok ? (unsigned)((tk % a.pos_rows) * a.N * 4) : kOob;
+#pragma unroll
+          for (int h0 = 0; h0 < NRT; h0 += kEB) {
+            f32x4 pv[kEB];
+#pragma unroll
+            for (int i = 0; i < kEB; ++i)
+              pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p_rs, prow + (unsigned)(((h0 + i) * 16 + 4 * g) * 4), 0, 0));
+#pragma unroll
+            for (int i = 0; i < kEB; ++i)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[h0 + i][c] + pv[i]), q_rs,
+                                                     row_o + (unsigned)(((h0 + i) * 16 + 4 * g) * 4), 0, 0);
           }
         }
       } else {
@@ -261,6 +324,7 @@ extern "C" int wm2f_token_linear_fwd(const void* x, const void* w, const void* b
   WM2F_REQUIRE(N == 256 || N == 288, "%s: N = %d is not built (256 and 288 are: the widths of the pixel decoder's narrow Linears)", who, N);
   WM2F_REQUIRE(K % kPhaseK == 0, "%s: K = %d must be a multiple of %d", who, K, kPhaseK);
   WM2F_REQUIRE(M * (int64_t)K * 4 < (1ll << 31) && M * (int64_t)N * 4 < (1ll << 31), "%s: x / out must stay below 2 GiB (32-bit buffer offsets)", who);
+  WM2F_REQUIRE(pos_rows * (int64_t)N * 4 < (1ll << 31), "%s: pos must stay below 2 GiB", who);
   WM2F_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "%s: LayerNorm needs both gamma and beta", who);
   WM2F_REQUIRE(!residual || ln_gamma, "%s: the residual belongs to the LayerNorm epilogue", who);
   WM2F_REQUIRE(!out_plus_pos || (pos && ln_gamma && pos_rows > 0), "%s: out_plus_pos needs pos, pos_rows and the LayerNorm epilogue", who);
@@ -293,7 +357,7 @@ extern "C" int wm2f_token_linear_fwd(const void* x, const void* w, const void* b
   a.tiles_total = (int)ceil_div64(M, 16);
   int grid = n_cu;
   if (grid > a.tiles_total) grid = a.tiles_total;
-  const size_t lds = (size_t)2 * (N / 16) * 4 * 64 * 4 * sizeof(float);
+  const size_t lds = (size_t)2 * (N / 16) * 4 * 64 * 4 * sizeof(float) + (size_t)3 * N * sizeof(float);
   auto kfn = N == 256 ? token_gemm_kernel<16, 1> : token_gemm_kernel<18, 1>;
 #ifdef WM2F_PROFILING
   {  // timing ablations (outputs not valid): WM2F_TG_MODE = 1 no x loads, 2 no LDS reads, 3 neither, 4 no barriers, 7 all
@@ -304,6 +368,8 @@ extern "C" int wm2f_token_linear_fwd(const void* x, const void* w, const void* b
     if (N == 256 && mode == 3) kfn = token_gemm_kernel<16, 1, 3>;
     if (N == 256 && mode == 4) kfn = token_gemm_kernel<16, 1, 4>;
     if (N == 256 && mode == 7) kfn = token_gemm_kernel<16, 1, 7>;
+    if (N == 256 && mode == 8) kfn = token_gemm_kernel<16, 1, 8>;
+    if (N == 256 && mode == 15) kfn = token_gemm_kernel<16, 1, 15>;
   }
 #endif
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
