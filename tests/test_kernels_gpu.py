@@ -675,3 +675,32 @@ def test_token_linear_fused_epilogues(ops, M, K, N, relu, ln, res, pos):
         bi = torch.randint(-5, 6, (N,), generator=g).float()
         exp = torch.nn.functional.linear(xi, wi, bi)
         assert torch.equal(ops.token_linear(dev(xi), dev(wi), dev(bi), relu=relu).cpu(), exp.relu() if relu else exp)
+
+
+@pytest.mark.parametrize("shapes,B", [([(25, 42), (50, 84), (100, 167)], 1), ([(7, 11), (13, 21), (25, 42)], 2),
+                                      ([(3, 5), (6, 9), (12, 17)], 2), ([(13, 13), (25, 25), (50, 50)], 1)])
+def test_k1_streaming_kernel_on_pyramids_that_are_not_1_2_4(ops, shapes, B):
+    """Input sizes that are not multiples of 32 (BASELINE config 5: 1333 x 800 -> 25x42 / 50x84 / 100x167) give level sizes
+    that only roughly double.  The streaming kernel takes them (variant 4 refuses a shape it cannot run, so a pass here IS
+    that kernel): queries mapped to tiles by their reference points, window origins by division, up to 5 x 5 + 9 x 9 + 16 x 16
+    queries a tile.  Both operand forms, local offsets (windows) and far ones (slow path), against the oracle and against
+    the direct-gather kernel."""
+    H, D, L, P = 8, 32, 3, 4
+    g = torch.Generator().manual_seed(21)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.float32)
+    for spread in (3.0, 12.0):
+        off = (torch.rand(B, S, H, L, P, 2, generator=g) * 2 - 1) * spread
+        logits = torch.randn(B, S, H, L * P, generator=g)
+        loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        aw = torch.softmax(logits, -1).view(B, S, H, L, P)
+        ref = O.msdeform_attn_core(value, shapes, loc, aw)
+        out_u = ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(aw), variant=4)
+        out_f = ops.ms_deform_attn_variant(dev(value), shapes, dev(off), dev(logits), dev(ref_pts), fused=True, variant=4)
+        out_d = ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(aw), variant=1)
+        torch.testing.assert_close(out_u.cpu(), ref, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out_f.cpu(), ref, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(out_u, out_d, rtol=1e-4, atol=1e-5)
+    assert not ops.k1_lanes_applies(shapes, S, D, P, B, H)  # the lane-major rows stay with the exact pyramids

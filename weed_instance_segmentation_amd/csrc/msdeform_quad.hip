@@ -42,10 +42,14 @@ template <int LV> struct Win {
 static_assert(Win<0>::per_wave == 4 && Win<1>::per_wave == 6 && Win<2>::per_wave == 11, "vmcnt constants below");
 
 struct QuadGeom {
-  int W0, H0;  // coarsest level; level l is (H0 << l, W0 << l)
+  int W0, H0;  // coarsest level; in an exact pyramid level l is (H0 << l, W0 << l)
   int tiles_x, tiles_y;
   int start[3];
   int a_qstride, b_qstride;
+  // streaming kernel, any 3-level pyramid ordered coarse -> fine (sizes that are not multiples of 32 give 25x42 / 50x84 /
+  // 100x167 ...): the level sizes, their reciprocals, and 1 / (2 W_fine), 1 / (2 H_fine) for the tile -> query arithmetic
+  int W[3], H[3], exact;
+  float inv_w[3], inv_h[3], inv_2wf, inv_2hf;
 };
 
 // MODE 7 (variant 73): the kernel with in-kernel time stamps (s_memtime, wave 0 of each workgroup),
@@ -634,6 +638,45 @@ struct TileId {
   int b, h, tx, ty, hh;  // hh: which 16-channel half of the head (half-head form), else 0
 };
 
+// One tile (16 x 16 finest-level pixels) seen from level l: the queries whose reference point (q + 0.5) / n falls into
+// the tile -- columns [qx0, qx0 + nqx), rows [qy0, qy0 + nqy) -- and the window origin, floor(first sampled pixel) - margin,
+// where a reference point x in [tx 16 / W_f, (tx + 1) 16 / W_f) lands on pixel x W_l - 0.5 of level l.  In an exact
+// 1 : 2 : 4 pyramid these are tx * f, f, tx * f - 1 - margin with f = 4 << l; in general they need a division per bound
+// (exact float divisions: the host checks the operands stay below 2^22).
+struct LevelTile {
+  int wx0, wy0, qx0, qy0, nqx, nqy;
+};
+__device__ __forceinline__ void axis_tile(int t, int n, int nf, float inv_2nf, int& w0, int& q0, int& nq) {
+  // first query at or beyond the tile's lower edge: q >= (2 t 16 n - nf) / (2 nf), rounded up (msdeform_tiled.h: q_lo)
+  auto lo = [&](int tt) {
+    const int a = 2 * tt * kQF * n - nf;
+    if (a <= 0) return 0;
+    const int v = div_small(a + 2 * nf - 1, 2 * nf, inv_2nf);
+    return v > n ? n : v;
+  };
+  q0 = lo(t);
+  nq = lo(t + 1) - q0;
+  const int a = 2 * t * kQF * n - nf;  // floor(t 16 n / nf - 0.5) = floor(a / (2 nf)); a < 0 only for t = 0: -1
+  w0 = (a < 0 ? -1 : div_small(a, 2 * nf, inv_2nf)) - kQM;
+}
+__device__ __forceinline__ LevelTile level_tile(const QuadGeom& g, int l, int tx, int ty) {
+  LevelTile r;
+  if (g.exact || l == 2) {
+    const int fq = kQF >> (2 - l);
+    r.qx0 = tx * fq;
+    r.qy0 = ty * fq;
+    r.wx0 = r.qx0 - 1 - kQM;
+    r.wy0 = r.qy0 - 1 - kQM;
+    const int nx = g.W[l] - r.qx0, ny = g.H[l] - r.qy0;
+    r.nqx = nx < 0 ? 0 : (nx > fq ? fq : nx);
+    r.nqy = ny < 0 ? 0 : (ny > fq ? fq : ny);
+    return r;
+  }
+  axis_tile(tx, g.W[l], g.W[2], g.inv_2wf, r.wx0, r.qx0, r.nqx);
+  axis_tile(ty, g.H[l], g.H[2], g.inv_2hf, r.wy0, r.qy0, r.nqy);
+  return r;
+}
+
 // Position of a persistent workgroup in its tile sequence (all wave-uniform): image, head, and the tile's index within
 // the image in WORK order.  One division chain at the start, then additions.
 struct TileWalk {
@@ -768,18 +811,18 @@ struct LoaderTile {  // wave-uniform per-tile values of the loaders
 __device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, const TileId& t, int S, int heads,
                                                   int pixel_bytes = 128) {
   const QuadGeom& g = sg.q;
-  const int row_stride = heads * 32, row_bytes = row_stride * 4, px0 = g.W0 * g.H0;
+  const int row_stride = heads * 32, row_bytes = row_stride * 4;
   const float* vb = value + ((int64_t)t.b * S * heads + t.h) * 32 + t.hh * 16;  // this head's slice (its second half: + 16 channels)
   LoaderTile lt;
   lt.x_border = false;
 #pragma unroll
   for (int l = 0; l < 3; ++l) {
-    const int Wl = g.W0 << l, fq = kQF >> (2 - l);
-    const int wx0 = t.tx * fq - 1 - kQM, wy0 = t.ty * fq - 1 - kQM;
-    lt.wx0[l] = wx0;
-    lt.tile_off[l] = (wy0 * Wl + wx0) * row_bytes;
-    lt.x_border = lt.x_border || wx0 < 0 || wx0 + Win<0>::side + (fq - (kQF >> 2)) > Wl;
-    const int npx = px0 << (2 * l);
+    const int Wl = g.W[l];
+    const LevelTile lv = level_tile(g, l, t.tx, t.ty);
+    lt.wx0[l] = lv.wx0;
+    lt.tile_off[l] = (lv.wy0 * Wl + lv.wx0) * row_bytes;
+    lt.x_border = lt.x_border || lv.wx0 < 0 || lv.wx0 + (l == 0 ? Win<0>::side : (l == 1 ? Win<1>::side : Win<2>::side)) > Wl;
+    const int npx = g.W[l] * g.H[l];
     lt.slab[l] = __builtin_amdgcn_make_buffer_rsrc((void*)(vb + (int64_t)g.start[l] * row_stride), 0,
                                                    (npx - 1) * row_bytes + pixel_bytes, 0x00020000);
   }
@@ -787,17 +830,20 @@ __device__ __forceinline__ LoaderTile loader_tile(const float* value, const Stre
 }
 
 // What a gather lane knows about "its" queries for one tile SHAPE (the numbers of queries per level in the tile: the
-// same for every interior tile), so that a tile costs a handful of instructions per pass instead of a decode:
+// same for every interior tile of an exact pyramid), so that a tile costs a handful of instructions per pass instead of a
+// decode:
 //   q_rel     row * W_lq + col of the query inside its own level, relative to the tile's first query of that level
-//   lq        the query's level (0 coarse .. 2 fine)
-//   cxs, cys  (col + 0.5) * 2^-lq, (row + 0.5) * 2^-lq: its reference point in COARSE-level pixels relative to the tile
-// With the tile's per-level first query (3 scalars) the token is q_rel + first[lq]; on level l the reference point sits
-// at pixel (tx * 4 * 2^l) + (cxs * 2^l - 0.5) -- both exact in fp32 (integers and eighths), so the sampling coordinate
-// `that + offset` is rounded once (the dependency rounds (q + 0.5) / W, + offset / W and * W - 0.5 in turn).
+//   lq        the query's level (0 coarse .. 2 fine);   col, row   its position among the tile's queries of that level
+// With the tile's per-level first query (3 scalars) the token is q_rel + first[lq] and the query's column qx0[lq] + col;
+// its reference point (qx + 0.5) / W_lq lands on pixel ref * W_l - 0.5 of level l (HF:993-1002 with grid_sample's
+// align_corners = False rule), to which the sampling offset is added.
+// Packed into one register per pass (the kernel sits at its 168-register cap): col | row << 8 | lq << 16 | valid << 31.
 struct PassConst {
-  int q_rel[kPasses], lq[kPasses];
-  float cxs[kPasses], cys[kPasses];
-  bool valid[kPasses];
+  unsigned code[kPasses];
+  __device__ __forceinline__ int col(int t) const { return (int)(code[t] & 255u); }
+  __device__ __forceinline__ int row(int t) const { return (int)((code[t] >> 8) & 255u); }
+  __device__ __forceinline__ int lq(int t) const { return (int)((code[t] >> 16) & 3u); }
+  __device__ __forceinline__ bool valid(int t) const { return (code[t] >> 31) != 0u; }
 };
 
 // ---- flags instead of workgroup barriers (SYNC = 1) ---------------------------------------------------------
@@ -858,9 +904,9 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     LoaderRegs<0> r0;
     LoaderRegs<1> r1;
     LoaderRegs<2> r2;
-    if (kLoaderTable<0, CH>) loader_init<0, CH>(r0, ld, g.W0, row_bytes, pix_lane, lane_part);
-    if (kLoaderTable<1, CH>) loader_init<1, CH>(r1, ld, g.W0 << 1, row_bytes, pix_lane, lane_part);
-    loader_init<2, CH>(r2, ld, g.W0 << 2, row_bytes, pix_lane, lane_part);
+    if (kLoaderTable<0, CH>) loader_init<0, CH>(r0, ld, g.W[0], row_bytes, pix_lane, lane_part);
+    if (kLoaderTable<1, CH>) loader_init<1, CH>(r1, ld, g.W[1], row_bytes, pix_lane, lane_part);
+    loader_init<2, CH>(r2, ld, g.W[2], row_bytes, pix_lane, lane_part);
     // Schedule (per loader; F = fine window split in two parts so that no phase carries much more than a third of
     // a tile's requests -- the requests are accepted at the memory side's pace, ~100 cycles each per loader, and
     // the gather waves wait for the loader at every barrier):
@@ -870,9 +916,9 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
     TileWalk walk = walk_init(first, sg, heads * kSplit);
     LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
-    loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
+    loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
     __builtin_amdgcn_sched_barrier(0);
-    loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
+    loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
     if (SYNC == 1) {
       for (int k = 0; k < n_my; ++k) {
         wait_vm<LWin<1>::n>();  // coarse(k) landed
@@ -880,17 +926,17 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         wait_vm<0>();           // mid(k) landed
         publish(&ctrl[kCtrlReady + 1 * 2 + ld], k + 1, lane);
         poll_ge(&ctrl[kCtrlDone + 2], kGW * k);  // every gather wave is done with fine(k - 1)
-        loader_issue<2, 0, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+        loader_issue<2, 0, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
         wait_vm<0>();
         publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
         if (k + 1 < n_my) {
           walk_step(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           poll_ge(&ctrl[kCtrlDone + 0], kGW * (k + 1));
-          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
+          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
           __builtin_amdgcn_sched_barrier(0);
           poll_ge(&ctrl[kCtrlDone + 1], kGW * (k + 1));
-          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
+          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
         }
       }
       return;
@@ -901,12 +947,12 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       WM2F_SSTAMP(10, kLoaderWave0);
       wg_barrier();           // Bc(k): gather waves are done with fine(k-1)
       WM2F_SSTAMP(11, kLoaderWave0);
-      loader_issue<2, 0, kFA, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      loader_issue<2, 0, kFA, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
       WM2F_SSTAMP(12, kLoaderWave0);
       wait_vm<kFA>();  // mid(k) landed
       wg_barrier();    // Bm(k): gather waves are done with coarse(k)
       WM2F_SSTAMP(13, kLoaderWave0);
-      loader_issue<2, kFA, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W0 << 2, pix_lane);
+      loader_issue<2, kFA, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
       if (sg.sched == 1) {
         // Per-wave stamps (profiles/r02_k1_stream_stamps_*.json): with coarse(k + 1) requested here the loaders were the
         // last to reach Bf(k) in every workgroup, 1.5k cycles behind the gather waves.  The coarse window is not needed
@@ -919,9 +965,9 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
           walk_step(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           __builtin_amdgcn_sched_barrier(0);
-          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
+          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
           __builtin_amdgcn_sched_barrier(0);
-          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
+          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
         }
         continue;
       }
@@ -929,7 +975,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         walk_step(walk, sg, heads * kSplit);
         lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
         __builtin_amdgcn_sched_barrier(0);
-        loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W0, pix_lane, lane_part, row_bytes);
+        loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
         wait_vm<LWin<0>::n>();  // fine(k) landed
       } else {
         wait_vm<0>();
@@ -939,7 +985,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       WM2F_SSTAMP(15, kLoaderWave0);
       if (more) {
         __builtin_amdgcn_s_sleep(24);  // ~1.5k cycles: leave the memory path to the gather waves' operand loads
-        loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W0 << 1, pix_lane, lane_part, row_bytes);
+        loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
       }
     }
     (void)kFB;
@@ -959,7 +1005,6 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_in, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_in, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
-  const float inv_w0 = __builtin_amdgcn_rcpf((float)g.W0), inv_h0 = __builtin_amdgcn_rcpf((float)g.H0);
 
   PassConst pc;
   int shape_key = -1;  // packed (nqx, nqy) per level of the tile shape `pc` was built for
@@ -969,19 +1014,19 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     float wt[kPasses][NL];
     int qrow[kPasses];  // b * Q + token
     bool valid[kPasses];
-    int wx0[NL], wy0[NL], b, h, tx, ty, hh;
+    int wx0[NL], wy0[NL], qx0[NL], qy0[NL], b, h, tx, ty, hh;
   };
   // reference point of token q (HF:1127-1156): ((column + 0.5) / W_l, (row + 0.5) / H_l) of its own level (slow path only)
   auto ref_point = [&](int q, float& rx, float& ry) __attribute__((always_inline)) {
     const int l = (q >= g.start[1] ? 1 : 0) + (q >= g.start[2] ? 1 : 0);
     const int rel = q - (l == 2 ? g.start[2] : (l == 1 ? g.start[1] : 0));
-    const int Wq = g.W0 << l;
-    const int qy = (int)(((float)rel + 0.5f) * __builtin_amdgcn_rcpf((float)Wq)) , r0 = rel - qy * Wq;
+    const int Wq = l == 2 ? g.W[2] : (l == 1 ? g.W[1] : g.W[0]);
+    const float iw = l == 2 ? g.inv_w[2] : (l == 1 ? g.inv_w[1] : g.inv_w[0]), ih = l == 2 ? g.inv_h[2] : (l == 1 ? g.inv_h[1] : g.inv_h[0]);
+    const int qy = (int)(((float)rel + 0.5f) * iw), r0 = rel - qy * Wq;
     const int qyc = r0 < 0 ? qy - 1 : (r0 >= Wq ? qy + 1 : qy);  // one correction step: rel can exceed 2^22 / W
     const int qx = rel - qyc * Wq;
-    const float sc = l == 2 ? 0.25f : (l == 1 ? 0.5f : 1.f);  // exact: rcp(W0 * 2^l) == rcp(W0) * 2^-l
-    rx = ((float)qx + 0.5f) * (inv_w0 * sc);
-    ry = ((float)qyc + 0.5f) * (inv_h0 * sc);
+    rx = ((float)qx + 0.5f) * iw;
+    ry = ((float)qyc + 0.5f) * ih;
   };
   const int a_row = g.a_qstride * 4, b_row = g.b_qstride * 4;  // bytes per token in the two operand arrays (< 2^24: host)
   auto fetch = [&](const TileId& t) __attribute__((always_inline)) {
@@ -994,14 +1039,15 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     int nqx[NL], nqy[NL], qfirst[NL], key = 0;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
-      o.wx0[l] = t.tx * fq - 1 - kQM;
-      o.wy0[l] = t.ty * fq - 1 - kQM;
-      int nx = Wl - t.tx * fq, ny = Hl - t.ty * fq;
-      nqx[l] = nx < 0 ? 0 : (nx > fq ? fq : nx);
-      nqy[l] = ny < 0 ? 0 : (ny > fq ? fq : ny);
+      const LevelTile lv = level_tile(g, l, t.tx, t.ty);
+      o.wx0[l] = lv.wx0;
+      o.wy0[l] = lv.wy0;
+      o.qx0[l] = lv.qx0;
+      o.qy0[l] = lv.qy0;
+      nqx[l] = lv.nqx;
+      nqy[l] = lv.nqy;
       key = key * 1024 + nqx[l] * 32 + nqy[l];
-      qfirst[l] = t.b * Q + g.start[l] + (t.ty * fq) * Wl + t.tx * fq;  // the tile's first token of level l
+      qfirst[l] = t.b * Q + g.start[l] + lv.qy0 * g.W[l] + lv.qx0;  // the tile's first token of level l
     }
     if (key != shape_key) {  // wave-uniform; interior tiles all share one shape
       shape_key = key;
@@ -1015,8 +1061,8 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         // Half-head form: 7 gather waves x 16 quads x 3 passes = 336 = a full tile's queries: every wave takes three passes.
         const int w3 = kGW == 7 ? wave : (kGW == 8 ? (wave < 4 ? wave : (wave == 7 ? 4 : 1 << 20)) : (wave == 2 ? 0 : 1 << 20));
         int qi = t2 < 2 ? slot + (kGW * 16) * t2 : 2 * (kGW * 16) + w3 * 16 + (quad & 8) + xq;
-        pc.valid[t2] = qi < nq;
-        if (!pc.valid[t2]) qi = 0;  // an empty slot shadows the tile's first query (a real token: loads stay in range)
+        const bool ok = qi < nq;
+        if (!ok) qi = 0;  // an empty slot shadows the tile's first query (a real token: loads stay in range)
         const bool ge1 = qi >= c1, ge2 = qi >= c2;
         const int lq = (ge1 ? 1 : 0) + (ge2 ? 1 : 0);
         const int nx = ge2 ? nqx[2] : (ge1 ? nqx[1] : nqx[0]);
@@ -1024,18 +1070,16 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         const int nxs = nx < 1 ? 1 : nx;
         const int ly_ = (int)(((float)loc_i + 0.5f) * __builtin_amdgcn_rcpf((float)nxs));  // exact: small integers
         const int lx_ = loc_i - ly_ * nxs;
-        const float sc = ge2 ? 0.25f : (ge1 ? 0.5f : 1.f);
-        pc.lq[t2] = lq;
-        pc.q_rel[t2] = (int)__umul24((unsigned)ly_, (unsigned)(g.W0 << lq)) + lx_;
-        pc.cxs[t2] = ((float)lx_ + 0.5f) * sc;
-        pc.cys[t2] = ((float)ly_ + 0.5f) * sc;
+        pc.code[t2] = (unsigned)lx_ | ((unsigned)ly_ << 8) | ((unsigned)lq << 16) | (ok ? 0x80000000u : 0u);
       }
     }
     const int ah = (t.h * (NL * P * 2) + j * 2) * 4, bh = (t.h * (NL * P) + j) * 4;
 #pragma unroll
     for (int t2 = 0; t2 < kPasses; ++t2) {
-      const int q = pc.q_rel[t2] + (pc.lq[t2] == 2 ? qfirst[2] : (pc.lq[t2] == 1 ? qfirst[1] : qfirst[0]));
-      o.valid[t2] = pc.valid[t2];
+      const int lq = pc.lq(t2);
+      const int q = (int)__umul24((unsigned)pc.row(t2), (unsigned)(lq == 2 ? g.W[2] : (lq == 1 ? g.W[1] : g.W[0]))) + pc.col(t2) +
+                    (lq == 2 ? qfirst[2] : (lq == 1 ? qfirst[1] : qfirst[0]));
+      o.valid[t2] = pc.valid(t2);
       o.qrow[t2] = q;
       const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
       const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
@@ -1088,15 +1132,22 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
 #pragma unroll
         for (int l = 0; l < NL; ++l) wt[t][l] *= inv;
       }
+      float refx = 0.f, refy = 0.f;
+      if (FUSED) {  // the query's reference point (`pc` still describes this tile: the next fetch comes later)
+        const int lq = pc.lq(t);
+        const int qx = pc.col(t) + (lq == 2 ? cur.qx0[2] : (lq == 1 ? cur.qx0[1] : cur.qx0[0]));
+        const int qy = pc.row(t) + (lq == 2 ? cur.qy0[2] : (lq == 1 ? cur.qy0[1] : cur.qy0[0]));
+        refx = ((float)qx + 0.5f) * (lq == 2 ? g.inv_w[2] : (lq == 1 ? g.inv_w[1] : g.inv_w[0]));
+        refy = ((float)qy + 0.5f) * (lq == 2 ? g.inv_h[2] : (lq == 1 ? g.inv_h[1] : g.inv_h[0]));
+      }
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
+        const float Wl = (float)g.W[l], Hl = (float)g.H[l];
         if (FUSED) {
-          // loc = ref + off / (W, H); pixel = loc * (W, H) - 0.5 == ref * W - 0.5 + off, with ref * W - 0.5 taken
-          // exactly: tile origin + (cxs * 2^l - 0.5) (`pc` still describes this tile: the next fetch comes later)
-          px[t][l] = ((float)(cur.tx << (l + 2)) + fmaf(pc.cxs[t], (float)(1 << l), -0.5f)) + cur.lc[t][l].x;
-          py[t][l] = ((float)(cur.ty << (l + 2)) + fmaf(pc.cys[t], (float)(1 << l), -0.5f)) + cur.lc[t][l].y;
+          // loc = ref + off / (W, H); pixel = loc * (W, H) - 0.5 == ref * W - 0.5 + off
+          px[t][l] = fmaf(refx, Wl, -0.5f) + cur.lc[t][l].x;
+          py[t][l] = fmaf(refy, Hl, -0.5f) + cur.lc[t][l].y;
         } else {
-          const float Wl = (float)(g.W0 << l), Hl = (float)(g.H0 << l);
           px[t][l] = ((2.f * cur.lc[t][l].x - 1.f + 1.f) * Wl - 1.f) * 0.5f;
           py[t][l] = ((2.f * cur.lc[t][l].y - 1.f + 1.f) * Hl - 1.f) * 0.5f;
         }
@@ -1180,7 +1231,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
           const int i = __ffs(todo) - 1;
           todo &= todo - 1;
           const int k2 = i / 3, l = i - k2 * 3;
-          const int Wl = g.W0 << l, Hl = g.H0 << l;
+          const int Wl = l == 2 ? g.W[2] : (l == 1 ? g.W[1] : g.W[0]), Hl = l == 2 ? g.H[2] : (l == 1 ? g.H[1] : g.H[0]);
           const int st_l = l == 0 ? g.start[0] : (l == 1 ? g.start[1] : g.start[2]);
           const float lx = lm ? ap[k2 * 9 + 2 * l] : ap[(l * P + k2) * 2], ly = lm ? ap[k2 * 9 + 2 * l + 1] : ap[(l * P + k2) * 2 + 1];
           float aw = logit_at(l * P + k2), x, y;
@@ -1275,26 +1326,57 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   *handled = false;
   if (P != 4 || L != 3 || (int64_t)Q != S) return WM2F_OK;
   const int H0 = level_hw[0], W0 = level_hw[1];
-  for (int l = 1; l < 3; ++l)
-    if (level_hw[2 * l] != (H0 << l) || level_hw[2 * l + 1] != (W0 << l)) return WM2F_OK;
-  if (H0 < 1 || W0 < 1 || (int64_t)H0 * W0 * 21 != S) return WM2F_OK;
+  bool exact = true;
+  int64_t tokens = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int Hl = level_hw[2 * l], Wl = level_hw[2 * l + 1];
+    if (Hl < 1 || Wl < 1) return WM2F_OK;
+    if (Hl != (H0 << l) || Wl != (W0 << l)) exact = false;
+    tokens += (int64_t)Hl * Wl;
+  }
+  if (tokens != S) return WM2F_OK;
+  if (!exact) {
+    // Any other coarse -> fine pyramid whose levels roughly double (input sizes that are not multiples of 32: 25x42 /
+    // 50x84 / 100x167): a 16 x 16 tile of the finest level must hold at most 4+1, 8+1 queries per axis of the two coarser
+    // levels (the slot count: 25 + 81 + 256 <= 384) and its sampling range must fit the compile-time windows; the float
+    // divisions of the tile -> query arithmetic must stay exact (operands below 2^22).  Full-head form only.
+    if (half || lanes) return WM2F_OK;
+    const int Wf = level_hw[5], Hf = level_hw[4];
+    for (int l = 0; l < 2; ++l) {
+      const int Hl = level_hw[2 * l], Wl = level_hw[2 * l + 1], fq = kQF >> (2 - l);
+      if ((int64_t)kQF * Wl > (int64_t)(fq + 1) * Wf - Wl || (int64_t)kQF * Hl > (int64_t)(fq + 1) * Hf - Hl) return WM2F_OK;  // <= fq + 1 queries per axis
+      if ((int64_t)kQF * Wl > (int64_t)fq * Wf + Wf || (int64_t)kQF * Hl > (int64_t)fq * Hf + Hf) return WM2F_OK;          // window: 16 W_l / W_f <= fq + 1
+      if ((int64_t)2 * kQF * ((Wf + kQF - 1) / kQF + 1) * Wl + 2 * Wf >= (1 << 22) ||
+          (int64_t)2 * kQF * ((Hf + kQF - 1) / kQF + 1) * Hl + 2 * Hf >= (1 << 22))
+        return WM2F_OK;
+    }
+  }
   StreamGeom sg;
   QuadGeom& g = sg.q;
   g.W0 = W0;
   g.H0 = H0;
-  g.tiles_x = (4 * W0 + kQF - 1) / kQF;
-  g.tiles_y = (4 * H0 + kQF - 1) / kQF;
-  g.start[0] = 0;
-  g.start[1] = H0 * W0;
-  g.start[2] = 5 * H0 * W0;
+  g.exact = exact ? 1 : 0;
+  int64_t start = 0;
+  for (int l = 0; l < 3; ++l) {
+    g.H[l] = level_hw[2 * l];
+    g.W[l] = level_hw[2 * l + 1];
+    g.inv_w[l] = 1.f / (float)g.W[l];
+    g.inv_h[l] = 1.f / (float)g.H[l];
+    g.start[l] = (int)start;
+    start += (int64_t)g.H[l] * g.W[l];
+  }
+  g.inv_2wf = 1.f / (float)(2 * g.W[2]);
+  g.inv_2hf = 1.f / (float)(2 * g.H[2]);
+  g.tiles_x = (g.W[2] + kQF - 1) / kQF;
+  g.tiles_y = (g.H[2] + kQF - 1) / kQF;
   g.a_qstride = a_qstride > 0 ? a_qstride : heads * L * P * 2;
   g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
   const int64_t n_logical = (int64_t)B * heads * split * g.tiles_x * g.tiles_y;
   const int64_t lim = 0x7fffffff;
   if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || g.b_qstride * 4 >= (1 << 24) ||
       (int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
-      (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)16 * H0 * W0 >= (1 << 24) || heads * 32 * 4 >= (1 << 24) ||
-      (int64_t)21 * H0 * W0 * heads * 32 * 4 >= lim)
+      (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)g.H[2] * g.W[2] >= (1 << 24) || heads * 32 * 4 >= (1 << 24) ||
+      (int64_t)S * heads * 32 * 4 >= lim)
     return WM2F_OK;
   static int n_cu = 0;
   if (n_cu == 0) {
