@@ -34,7 +34,11 @@ def main():
     ap.add_argument("--smooth", action="store_true", help="K1: slowly varying offsets instead of independent uniform ones")
     ap.add_argument("--init", action="store_true", help="K1: the module's initial offset pattern (point i of head h sits (i + 1) px along direction h, HF:2154-2166) -- what bench.py's random-init model feeds the kernel")
     ap.add_argument("--prof", action="store_true", help="load libwm2f_prof.so: K1 timing ablations (variant 44 ...), WM2F_K2_* / WM2F_K3_DBG environment knobs")
+    ap.add_argument("--lib", default=None, help="load this build of libwm2f.so instead (A/B of two builds of the library on one box, e.g. the previous commit's)")
     a = ap.parse_args()
+    if a.lib:
+        from weed_instance_segmentation_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     if a.prof:
         from weed_instance_segmentation_amd import _lib
         _lib.use_profiling_library()

@@ -26,6 +26,7 @@
 //
 // Roofline: HBM, algorithmic bytes as msdeform.hip (550 502 400 B per launch at config 2).
 #include "msdeform_tiled.h"
+#include <type_traits>
 
 namespace wm2f {
 
@@ -837,13 +838,23 @@ __device__ __forceinline__ LoaderTile loader_tile(const float* value, const Stre
 // With the tile's per-level first query (3 scalars) the token is q_rel + first[lq] and the query's column qx0[lq] + col;
 // its reference point (qx + 0.5) / W_lq lands on pixel ref * W_l - 0.5 of level l (HF:993-1002 with grid_sample's
 // align_corners = False rule), to which the sampling offset is added.
-// Packed into one register per pass (the kernel sits at its 168-register cap): col | row << 8 | lq << 16 | valid << 31.
+// General pyramids: packed into one register per pass (the kernel sits at its 168-register cap):
+// col | row << 8 | lq << 16 | valid << 31.
 struct PassConst {
   unsigned code[kPasses];
   __device__ __forceinline__ int col(int t) const { return (int)(code[t] & 255u); }
   __device__ __forceinline__ int row(int t) const { return (int)((code[t] >> 8) & 255u); }
   __device__ __forceinline__ int lq(int t) const { return (int)((code[t] >> 16) & 3u); }
   __device__ __forceinline__ bool valid(int t) const { return (code[t] >> 31) != 0u; }
+};
+// Exact 1 : 2 : 4 pyramids (the encoder's own shape; the kernel template is instantiated for them separately: the general
+// arithmetic cost the production shape 15 %, profiles/r02_kbench_k1_general_vs_exact.jsonl): a query's reference point sits
+// at pixel (tx * 4 * 2^l) + (cxs * 2^l - 0.5) of level l with cxs = (col + 0.5) * 2^-lq -- integers and eighths, exact in
+// fp32, so the sampling coordinate `that + offset` is rounded once.
+struct PassConstExact {
+  int q_rel[kPasses], lq[kPasses];
+  float cxs[kPasses], cys[kPasses];
+  bool valid[kPasses];
 };
 
 // ---- flags instead of workgroup barriers (SYNC = 1) ---------------------------------------------------------
@@ -870,7 +881,7 @@ __device__ __forceinline__ void wave_done(int* p, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool FUSED, int MODE, int SYNC = 0, int CH = 8>
+template <bool FUSED, int MODE, int SYNC = 0, int CH = 8, bool EXACT = true>
 __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_stream_fwd_kernel(
     const float* __restrict__ value, const float* __restrict__ a_in, const float* __restrict__ b_in, float* __restrict__ out,
     StreamGeom sg, int S, int Q, int heads) {
@@ -1006,7 +1017,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_in, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
 
-  PassConst pc;
+  typename std::conditional<EXACT, PassConstExact, PassConst>::type pc;
   int shape_key = -1;  // packed (nqx, nqy) per level of the tile shape `pc` was built for
   // operands of a tile: raw loads + where they go
   struct Ops {
@@ -1039,15 +1050,25 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     int nqx[NL], nqy[NL], qfirst[NL], key = 0;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      const LevelTile lv = level_tile(g, l, t.tx, t.ty);
-      o.wx0[l] = lv.wx0;
-      o.wy0[l] = lv.wy0;
-      o.qx0[l] = lv.qx0;
-      o.qy0[l] = lv.qy0;
-      nqx[l] = lv.nqx;
-      nqy[l] = lv.nqy;
+      if constexpr (EXACT) {
+        const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
+        o.wx0[l] = t.tx * fq - 1 - kQM;
+        o.wy0[l] = t.ty * fq - 1 - kQM;
+        int nx = Wl - t.tx * fq, ny = Hl - t.ty * fq;
+        nqx[l] = nx < 0 ? 0 : (nx > fq ? fq : nx);
+        nqy[l] = ny < 0 ? 0 : (ny > fq ? fq : ny);
+        qfirst[l] = t.b * Q + g.start[l] + (t.ty * fq) * Wl + t.tx * fq;  // the tile's first token of level l
+      } else {
+        const LevelTile lv = level_tile(g, l, t.tx, t.ty);
+        o.wx0[l] = lv.wx0;
+        o.wy0[l] = lv.wy0;
+        o.qx0[l] = lv.qx0;
+        o.qy0[l] = lv.qy0;
+        nqx[l] = lv.nqx;
+        nqy[l] = lv.nqy;
+        qfirst[l] = t.b * Q + g.start[l] + lv.qy0 * g.W[l] + lv.qx0;
+      }
       key = key * 1024 + nqx[l] * 32 + nqy[l];
-      qfirst[l] = t.b * Q + g.start[l] + lv.qy0 * g.W[l] + lv.qx0;  // the tile's first token of level l
     }
     if (key != shape_key) {  // wave-uniform; interior tiles all share one shape
       shape_key = key;
@@ -1070,16 +1091,31 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         const int nxs = nx < 1 ? 1 : nx;
         const int ly_ = (int)(((float)loc_i + 0.5f) * __builtin_amdgcn_rcpf((float)nxs));  // exact: small integers
         const int lx_ = loc_i - ly_ * nxs;
-        pc.code[t2] = (unsigned)lx_ | ((unsigned)ly_ << 8) | ((unsigned)lq << 16) | (ok ? 0x80000000u : 0u);
+        if constexpr (EXACT) {
+          const float sc = ge2 ? 0.25f : (ge1 ? 0.5f : 1.f);
+          pc.valid[t2] = ok;
+          pc.lq[t2] = lq;
+          pc.q_rel[t2] = (int)__umul24((unsigned)ly_, (unsigned)(g.W0 << lq)) + lx_;
+          pc.cxs[t2] = ((float)lx_ + 0.5f) * sc;
+          pc.cys[t2] = ((float)ly_ + 0.5f) * sc;
+        } else {
+          pc.code[t2] = (unsigned)lx_ | ((unsigned)ly_ << 8) | ((unsigned)lq << 16) | (ok ? 0x80000000u : 0u);
+        }
       }
     }
     const int ah = (t.h * (NL * P * 2) + j * 2) * 4, bh = (t.h * (NL * P) + j) * 4;
 #pragma unroll
     for (int t2 = 0; t2 < kPasses; ++t2) {
-      const int lq = pc.lq(t2);
-      const int q = (int)__umul24((unsigned)pc.row(t2), (unsigned)(lq == 2 ? g.W[2] : (lq == 1 ? g.W[1] : g.W[0]))) + pc.col(t2) +
-                    (lq == 2 ? qfirst[2] : (lq == 1 ? qfirst[1] : qfirst[0]));
-      o.valid[t2] = pc.valid(t2);
+      int q;
+      if constexpr (EXACT) {
+        q = pc.q_rel[t2] + (pc.lq[t2] == 2 ? qfirst[2] : (pc.lq[t2] == 1 ? qfirst[1] : qfirst[0]));
+        o.valid[t2] = pc.valid[t2];
+      } else {
+        const int lq = pc.lq(t2);
+        q = (int)__umul24((unsigned)pc.row(t2), (unsigned)(lq == 2 ? g.W[2] : (lq == 1 ? g.W[1] : g.W[0]))) + pc.col(t2) +
+            (lq == 2 ? qfirst[2] : (lq == 1 ? qfirst[1] : qfirst[0]));
+        o.valid[t2] = pc.valid(t2);
+      }
       o.qrow[t2] = q;
       const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
       const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
@@ -1133,7 +1169,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         for (int l = 0; l < NL; ++l) wt[t][l] *= inv;
       }
       float refx = 0.f, refy = 0.f;
-      if (FUSED) {  // the query's reference point (`pc` still describes this tile: the next fetch comes later)
+      if constexpr (FUSED && !EXACT) {  // the query's reference point (`pc` still describes this tile: the next fetch comes later)
         const int lq = pc.lq(t);
         const int qx = pc.col(t) + (lq == 2 ? cur.qx0[2] : (lq == 1 ? cur.qx0[1] : cur.qx0[0]));
         const int qy = pc.row(t) + (lq == 2 ? cur.qy0[2] : (lq == 1 ? cur.qy0[1] : cur.qy0[0]));
@@ -1142,12 +1178,16 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       }
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        const float Wl = (float)g.W[l], Hl = (float)g.H[l];
-        if (FUSED) {
-          // loc = ref + off / (W, H); pixel = loc * (W, H) - 0.5 == ref * W - 0.5 + off
-          px[t][l] = fmaf(refx, Wl, -0.5f) + cur.lc[t][l].x;
-          py[t][l] = fmaf(refy, Hl, -0.5f) + cur.lc[t][l].y;
+        if constexpr (FUSED && EXACT) {
+          // loc = ref + off / (W, H); pixel = loc * (W, H) - 0.5 == ref * W - 0.5 + off, with ref * W - 0.5 taken
+          // exactly: tile origin + (cxs * 2^l - 0.5)
+          px[t][l] = ((float)(cur.tx << (l + 2)) + fmaf(pc.cxs[t], (float)(1 << l), -0.5f)) + cur.lc[t][l].x;
+          py[t][l] = ((float)(cur.ty << (l + 2)) + fmaf(pc.cys[t], (float)(1 << l), -0.5f)) + cur.lc[t][l].y;
+        } else if constexpr (FUSED) {
+          px[t][l] = fmaf(refx, (float)g.W[l], -0.5f) + cur.lc[t][l].x;
+          py[t][l] = fmaf(refy, (float)g.H[l], -0.5f) + cur.lc[t][l].y;
         } else {
+          const float Wl = (float)g.W[l], Hl = (float)g.H[l];
           px[t][l] = ((2.f * cur.lc[t][l].x - 1.f + 1.f) * Wl - 1.f) * 0.5f;
           py[t][l] = ((2.f * cur.lc[t][l].y - 1.f + 1.f) * Hl - 1.f) * 0.5f;
         }
@@ -1340,7 +1380,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
     // 50x84 / 100x167): a 16 x 16 tile of the finest level must hold at most 4+1, 8+1 queries per axis of the two coarser
     // levels (the slot count: 25 + 81 + 256 <= 384) and its sampling range must fit the compile-time windows; the float
     // divisions of the tile -> query arithmetic must stay exact (operands below 2^22).  Full-head form only.
-    if (half || lanes) return WM2F_OK;
+    if (half || lanes || mode == 100 || mode == 4 || mode == 7 || mode == 74) return WM2F_OK;
     const int Wf = level_hw[5], Hf = level_hw[4];
     for (int l = 0; l < 2; ++l) {
       const int Hl = level_hw[2 * l], Wl = level_hw[2 * l + 1], fq = kQF >> (2 - l);
@@ -1410,19 +1450,20 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
   sg.sched = (mode == 300) ? 0 : 1;  // mode 300: the round-1 loader schedule (A/B measurement)
   sg.lanes = lanes;
-  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 4>;
-  int threads = SCfg<4>::THREADS;
-  if (!half) {
-    kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8>;
-    threads = SCfg<8>::THREADS;
+  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true>;
+  int threads = SCfg<8>::THREADS;
+  if (!exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false>;
+  if (half) {
+    kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 4, true>;
+    threads = SCfg<4>::THREADS;
   }
 #ifdef WM2F_PROFILING
-  if (mode == 4) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8>;
-  if (mode == 7) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8>;
-  if (mode == 74) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 4>;
+  if (mode == 4 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true>;
+  if (mode == 7 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true>;
+  if (mode == 74 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 4, true>;
 #endif
-  if (mode == 100) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8>;  // flags instead of barriers
-  // (modes 200 / 300: the half-head kernel in raster tile order / with the round-1 loader schedule -- set above)
+  if (mode == 100 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8, true>;  // flags instead of barriers
+  // (modes 200 / 300: the same kernel in strip tile order / with the round-1 loader schedule -- set above)
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(threads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();
