@@ -17,6 +17,7 @@ NAMES = ["setup+operand loads issue", "DMA issue", "wait coarse(+operands)", "so
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", type=int, default=73)
+    ap.add_argument("--lanes", action="store_true", help="variant 74 on the lane-major operand rows (the model's inference path): sets WM2F_K1_STAMP=1 for the profiling library")
     ap.add_argument("--init", action="store_true", help="the module's initial offset pattern instead of uniform offsets in [-4, 4]")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -36,8 +37,19 @@ def main():
     ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
                      for h, w in shapes]).to(dev)
     refl = ref[:, None, :].expand(S, L, 2).contiguous()
+    if a.lanes:
+        os.environ["WM2F_K1_STAMP"] = "1"
+        lanes = torch.empty(B, S, H, P, 9, device=dev)
+        for l in range(L):
+            lanes[..., 2 * l] = off[:, :, :, l, :, 0]
+            lanes[..., 2 * l + 1] = off[:, :, :, l, :, 1]
+            lanes[..., 6 + l] = logits.view(B, S, H, L, P)[:, :, :, l, :]
+        lanes = lanes.reshape(B, S, H * 36).contiguous()
     for _ in range(3):
-        ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
+        if a.lanes:
+            ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H)
+        else:
+            ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
     torch.cuda.synchronize()
     n_wg = B * H * 64 if a.variant == 73 else torch.cuda.get_device_properties(0).multi_processor_count * (2 if a.variant == 84 else 1)
     buf = np.zeros((min(n_wg, 8192), 160), dtype=np.int64)

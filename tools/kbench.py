@@ -171,6 +171,20 @@ def main():
             logits = ops.mask_einsum(emb, pix)
             for hw in shapes:
                 res[f"attn_mask_build_{hw[0]}"] = timeit(lambda: ops.attn_mask_build(logits, hw), a.iters)
+    if "k1c5" in only:  # K1 at BASELINE config 5's level sizes (1333 x 800 unpadded: NOT 1:2:4): streaming kernel against its fallbacks
+        sh5 = [(25, 42), (50, 84), (100, 167)]
+        S5 = sum(h * w for h, w in sh5)
+        value = torch.randn(B, S5, H, D, device=dev)
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
+                         for h, w in sh5]).to(dev)
+        refl = ref[:, None, :].expand(S5, L, 2).contiguous()
+        off = torch.rand(B, S5, H, L, P, 2, device=dev) * 8.0 - 4.0
+        logits = torch.randn(B, S5, H, L * P, device=dev)
+        nb5 = 4 * (2 * value.numel() + off.numel() + logits.numel())
+        for variant, name in ((4, "streaming_general"), (2, "lds_window_kernel"), (1, "direct_gather")):
+            r = timeit(lambda: ops.ms_deform_attn_variant(value, sh5, off, logits, refl, fused=True, variant=variant), a.iters)
+            r.update(bytes=nb5, GBps=nb5 / r["med_us"] / 1e3)
+            res[f"k1_config5_levels_{name}"] = r
     if "tg" in only:  # token GEMMs of the encoder layers: wm2f_token_linear_fwd against the library (F.linear) + the separate LayerNorm pass
         import torch.nn.functional as F
         Mtok = B * S

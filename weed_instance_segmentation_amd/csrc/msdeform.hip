@@ -434,7 +434,11 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
   bool handled = false;
   if (D == 32 && L == 3 && P == 4) {
     const int row = heads * L * P * 3;
-    if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, 0, row,
+    int smode = 0;
+#ifdef WM2F_PROFILING
+    if (const char* e = getenv("WM2F_K1_STAMP")) smode = atoi(e) ? 7 : 0;  // profiling build: the stamped kernel on the lane-major rows
+#endif
+    if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, row,
                                      row, 1))
       return rc;
   }

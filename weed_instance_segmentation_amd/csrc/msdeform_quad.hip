@@ -622,6 +622,7 @@ struct StreamGeom {
   // no faster than raster (165 vs 169 us), so raster stays the default.
   int strip_w, full_strips, rem_w;
   float inv_per_strip, inv_strip_w, inv_rem_w;
+  int all_full;  // exact pyramid whose level sides are multiples of the tile (4, 8, 16): every tile has the full query counts
   int sched;   // loader schedule: 0 = coarse(k + 1) requested under the mid gather of tile k, 1 = behind Bf(k)
   int lanes;   // operand layout of the fused form: 0 = [offsets | logits] per token, 1 = lane-major (see fetch)
 };
@@ -681,8 +682,27 @@ __device__ __forceinline__ LevelTile level_tile(const QuadGeom& g, int l, int tx
 // Position of a persistent workgroup in its tile sequence (all wave-uniform): image, head, and the tile's index within
 // the image in WORK order.  One division chain at the start, then additions.
 struct TileWalk {
-  int b, h, tile;
+  int b, h, tile, tx, ty;  // tx, ty: kept incrementally in raster order (no division on the per-tile path)
 };
+// `split` = workgroups per (image, head, tile): the walk's innermost index is head * split + half
+__device__ __forceinline__ void walk_xy(TileWalk& w, const StreamGeom& sg) {  // (tx, ty) of w.tile by division: start-up and strip order
+  if (sg.strip_w <= 0) {
+    w.ty = div_small(w.tile, sg.q.tiles_x, sg.inv_tiles_x);
+    w.tx = w.tile - w.ty * sg.q.tiles_x;
+    return;
+  }
+  const int per_strip = sg.strip_w * sg.q.tiles_y;
+  const int s = div_small(w.tile, per_strip, sg.inv_per_strip);
+  if (s >= sg.full_strips) {  // the narrower last strip (tiles_x not a multiple of strip_w)
+    const int r = w.tile - sg.full_strips * per_strip;
+    w.ty = div_small(r, sg.rem_w, sg.inv_rem_w);
+    w.tx = sg.full_strips * sg.strip_w + (r - w.ty * sg.rem_w);
+    return;
+  }
+  const int r = w.tile - s * per_strip;
+  w.ty = div_small(r, sg.strip_w, sg.inv_strip_w);
+  w.tx = s * sg.strip_w + (r - w.ty * sg.strip_w);
+}
 __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int heads) {
   TileWalk w;
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
@@ -690,43 +710,43 @@ __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int 
   w.h = id - bt * heads;
   w.b = div_small(bt, n_tiles, sg.inv_ntiles);
   w.tile = bt - w.b * n_tiles;
+  walk_xy(w, sg);
   return w;
 }
+// Next tile of this workgroup: `step_h` heads and `step_t` tiles further.  In raster order the tile coordinates advance with
+// a few scalar adds and compares per step (per-wave stamps: the division chains, the kernel-argument reloads they dragged in
+// and the waits behind them had made this block 3 - 6 k cycles of a 21 k-cycle tile).
 __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int heads) {
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
+  int adv = sg.step_t;
   w.h += sg.step_h;
   if (w.h >= heads) {
     w.h -= heads;
-    ++w.tile;
+    ++adv;
   }
-  w.tile += sg.step_t;
+  w.tile += adv;
   while (w.tile >= n_tiles) {
     w.tile -= n_tiles;
     ++w.b;
   }
+  if (sg.strip_w > 0) {
+    walk_xy(w, sg);
+    return;
+  }
+  for (int i = 0; i < adv; ++i) {
+    if (++w.tx == sg.q.tiles_x) {
+      w.tx = 0;
+      if (++w.ty == sg.q.tiles_y) w.ty = 0;
+    }
+  }
 }
-// `split` = workgroups per (image, head, tile): the walk's innermost index is head * split + half
 __device__ __forceinline__ TileId walk_tile(const TileWalk& w, const StreamGeom& sg, int split = 1) {
   TileId t;
   t.b = w.b;
   t.h = split == 2 ? w.h >> 1 : w.h;
   t.hh = split == 2 ? w.h & 1 : 0;
-  if (sg.strip_w <= 0) {
-    t.ty = div_small(w.tile, sg.q.tiles_x, sg.inv_tiles_x);
-    t.tx = w.tile - t.ty * sg.q.tiles_x;
-    return t;
-  }
-  const int per_strip = sg.strip_w * sg.q.tiles_y;
-  int s = div_small(w.tile, per_strip, sg.inv_per_strip);
-  if (s >= sg.full_strips) {  // the narrower last strip (tiles_x not a multiple of strip_w)
-    const int r = w.tile - sg.full_strips * per_strip;
-    t.ty = div_small(r, sg.rem_w, sg.inv_rem_w);
-    t.tx = sg.full_strips * sg.strip_w + (r - t.ty * sg.rem_w);
-    return t;
-  }
-  const int r = w.tile - s * per_strip;
-  t.ty = div_small(r, sg.strip_w, sg.inv_strip_w);
-  t.tx = s * sg.strip_w + (r - t.ty * sg.strip_w);
+  t.tx = w.tx;
+  t.ty = w.ty;
   return t;
 }
 
@@ -1051,12 +1071,17 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       if constexpr (EXACT) {
+        // (window origins are tx * fq - 1 - margin: recomputed where they are used instead of carried in `Ops` -- the
+        // kernel's scalar registers are its scarcest resource: every per-tile scalar spilled is a v_readlane or, worse, a
+        // kernel-argument reload with its wait on the tile's critical path)
         const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
-        o.wx0[l] = t.tx * fq - 1 - kQM;
-        o.wy0[l] = t.ty * fq - 1 - kQM;
-        int nx = Wl - t.tx * fq, ny = Hl - t.ty * fq;
-        nqx[l] = nx < 0 ? 0 : (nx > fq ? fq : nx);
-        nqy[l] = ny < 0 ? 0 : (ny > fq ? fq : ny);
+        if (sg.all_full) {  // level sides are multiples of the tile: every tile holds fq x fq queries of level l
+          nqx[l] = nqy[l] = fq;
+        } else {
+          int nx = Wl - t.tx * fq, ny = Hl - t.ty * fq;
+          nqx[l] = nx < 0 ? 0 : (nx > fq ? fq : nx);
+          nqy[l] = ny < 0 ? 0 : (ny > fq ? fq : ny);
+        }
         qfirst[l] = t.b * Q + g.start[l] + (t.ty * fq) * Wl + t.tx * fq;  // the tile's first token of level l
       } else {
         const LevelTile lv = level_tile(g, l, t.tx, t.ty);
@@ -1201,6 +1226,8 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       slow[t] = 0;
     }
     const bool skip_last = __builtin_amdgcn_ballot_w64(cur.valid[kPasses - 1]) == 0;
+    auto wx0_of = [&](int l) __attribute__((always_inline)) { return EXACT ? cur.tx * (kQF >> (2 - l)) - 1 - kQM : cur.wx0[l]; };
+    auto wy0_of = [&](int l) __attribute__((always_inline)) { return EXACT ? cur.ty * (kQF >> (2 - l)) - 1 - kQM : cur.wy0[l]; };
 
     auto window_ready = [&](int w) __attribute__((always_inline)) {
       if (SYNC == 1) {
@@ -1213,12 +1240,12 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     WM2F_SSTAMP(1, 0);
     window_ready(0);  // Bc(k)
     WM2F_SSTAMP(2, 0);
-    gather_phase<0, MODE, true, CH>(win0, acc, px, py, wt, cur.valid, cur.wx0[0], cur.wy0[0], slow, off1, off2, skip_last);
+    gather_phase<0, MODE, true, CH>(win0, acc, px, py, wt, cur.valid, wx0_of(0), wy0_of(0), slow, off1, off2, skip_last);
     if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 0], lane);
     WM2F_SSTAMP(3, 0);
     window_ready(1);  // Bm(k)
     WM2F_SSTAMP(4, 0);
-    gather_phase<1, MODE, true, CH>(win1, acc, px, py, wt, cur.valid, cur.wx0[1], cur.wy0[1], slow, off1, off2, skip_last);
+    gather_phase<1, MODE, true, CH>(win1, acc, px, py, wt, cur.valid, wx0_of(1), wy0_of(1), slow, off1, off2, skip_last);
     if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 1], lane);
     WM2F_SSTAMP(5, 0);
     window_ready(2);  // Bf(k)
@@ -1229,7 +1256,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     }
     __builtin_amdgcn_sched_barrier(0);
     WM2F_SSTAMP(7, 0);
-    gather_phase<2, MODE, true, CH>(win2, acc, px, py, wt, cur.valid, cur.wx0[2], cur.wy0[2], slow, off1, off2, skip_last);
+    gather_phase<2, MODE, true, CH>(win2, acc, px, py, wt, cur.valid, wx0_of(2), wy0_of(2), slow, off1, off2, skip_last);
     if (SYNC == 1) wave_done(&ctrl[kCtrlDone + 2], lane);
     WM2F_SSTAMP(8, 0);
     if (CH == 4 && k + 1 < n_my) {
@@ -1448,6 +1475,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_per_strip = sg.strip_w ? 1.f / (float)(sg.strip_w * g.tiles_y) : 0.f;
   sg.inv_strip_w = sg.strip_w ? 1.f / (float)sg.strip_w : 0.f;
   sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
+  sg.all_full = (exact && g.W[2] % kQF == 0 && g.H[2] % kQF == 0) ? 1 : 0;
   sg.sched = (mode == 300) ? 0 : 1;  // mode 300: the round-1 loader schedule (A/B measurement)
   sg.lanes = lanes;
   auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true>;
