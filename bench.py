@@ -185,7 +185,7 @@ def main():
             nbytes = 4 * (2 * B * Stok * H * D + B * Stok * H * L * P * 3)
             ach = nbytes / us / 1e3
             traffic = None  # HBM bytes per launch from PMC counters of a separate rocprofv3 run (profiles/)
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_k1_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r02_pmc_k1_traffic.json")
             if B == 8 and S == 1024 and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
             line["roofline"] = {"kernel": k1_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,

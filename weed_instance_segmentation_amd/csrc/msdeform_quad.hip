@@ -28,6 +28,18 @@
 #include "msdeform_tiled.h"
 #include <type_traits>
 
+// Cache-policy bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1) of the streaming kernel's three global streams: window DMA,
+// operand rows, output rows.  Overridable at compile time for A/B builds (tools/kbench.py --lib).
+#ifndef WM2F_DMA_AUX
+#define WM2F_DMA_AUX 0
+#endif
+#ifndef WM2F_OP_AUX
+#define WM2F_OP_AUX 0
+#endif
+#ifndef WM2F_ST_AUX
+#define WM2F_ST_AUX 0
+#endif
+
 namespace wm2f {
 
 namespace {
@@ -796,7 +808,7 @@ __device__ __forceinline__ void loader_issue(lds4_t win, const LoaderRegs<LV>& r
       const unsigned rel = __umul24(__umul24(wy, (unsigned)Wl) + wx, (unsigned)row_bytes) + lane_part;
       const int x = wx0 + (int)wx;
       const unsigned off = (!x_border || (unsigned)x < (unsigned)Wl) ? rel + (unsigned)tile_off : kOobOffset;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, WM2F_DMA_AUX);
     }
     return;
   }
@@ -805,7 +817,7 @@ __device__ __forceinline__ void loader_issue(lds4_t win, const LoaderRegs<LV>& r
     for (int i = I0; i < I1; ++i) {
       int c = ld + kLoaders * i;
       c = c < kChunks ? c : kChunks - 1;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)(r.rel[i] + (unsigned)tile_off), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)(r.rel[i] + (unsigned)tile_off), 0, 0, WM2F_DMA_AUX);
     }
   } else {
     // the columns are tile-invariant too, but 77 more live registers do not fit: recompute them per use (the
@@ -818,7 +830,7 @@ __device__ __forceinline__ void loader_issue(lds4_t win, const LoaderRegs<LV>& r
       const unsigned idx = (unsigned)(c * kPPP) + pix_lane;
       const int x = wx0 + (int)(idx - (idx / (unsigned)W::side) * (unsigned)W::side);
       const unsigned off = ((unsigned)x < (unsigned)Wl) ? r.rel[i] + (unsigned)tile_off : kOobOffset;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(slab, (lptr_t)(win + c * 64), 16, (int)off, 0, 0, WM2F_DMA_AUX);
     }
   }
 }
@@ -1151,19 +1163,19 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         // in the texture-address unit behind the loaders' traffic: the per-wave stamps showed 3.0k cycles for the older and
         // 5.5k for the younger wave of each SIMD in this fetch)
         const int off = (int)__umul24((unsigned)q, (unsigned)a_row) + (t.h * 36 + j * 9) * 4;
-        const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
-        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, 0));
+        const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, WM2F_OP_AUX));
+        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, WM2F_OP_AUX));
         o.lc[t2][0] = make_float2(A.x, A.y);
         o.lc[t2][1] = make_float2(A.z, A.w);
         o.lc[t2][2] = make_float2(Bq.x, Bq.y);
         o.wt[t2][0] = Bq.z;
         o.wt[t2][1] = Bq.w;
-        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 32, 0, 0));
+        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 32, 0, WM2F_OP_AUX));
       } else {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-          o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, 0));
-          o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, 0));
+          o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, WM2F_OP_AUX));
+          o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, WM2F_OP_AUX));
         }
       }
     }
@@ -1316,8 +1328,8 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         }
       }
       const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4) + cur.hh * 64) : kOobOffset;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, 0);
-      if (CH == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, WM2F_ST_AUX);
+      if (CH == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, WM2F_ST_AUX);
     }
     WM2F_SSTAMP(9, 0);
   }
