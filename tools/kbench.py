@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--smooth", action="store_true", help="K1: slowly varying offsets instead of independent uniform ones")
     ap.add_argument("--init", action="store_true", help="K1: the module's initial offset pattern (point i of head h sits (i + 1) px along direction h, HF:2154-2166) -- what bench.py's random-init model feeds the kernel")
     ap.add_argument("--prof", action="store_true", help="load libwm2f_prof.so: K1 timing ablations (variant 44 ...), WM2F_K2_* / WM2F_K3_DBG environment knobs")
+    ap.add_argument("--fine-only", action="store_true", help="K2: the finest level (N = 16384) only, so that a counter pass averages one shape")
     ap.add_argument("--lib", default=None, help="load this build of libwm2f.so instead (A/B of two builds of the library on one box, e.g. the previous commit's)")
     a = ap.parse_args()
     if a.lib:
@@ -239,7 +240,7 @@ def main():
     if "k2" in only:
         E = H * D
         q = torch.randn(B, Q, E, device=dev) * 0.3
-        for hw in shapes:
+        for hw in (shapes[-1:] if a.fine_only else shapes):
             N = hw[0] * hw[1]
             k = torch.randn(B, N, E, device=dev)
             v = torch.randn(B, N, E, device=dev)

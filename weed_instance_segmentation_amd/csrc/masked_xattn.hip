@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
   constexpr int QL = NQT * 16;
   constexpr int RS = D + 4;
   constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+  constexpr float kTau = 8.f;  // lazy-rescale slack, log2 units
   __shared__ __attribute__((aligned(16))) float part[kXWaves][QL][RS];
 
   const int lane = threadIdx.x & 63;
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
   const uint32_t v_voff = (uint32_t)((4 * g * E + h * D + n) * 4);       // V^T: lane (d = 16 i + n, key0 + 4 g + t)
   uint32_t m_voff[NQT];                                                   // mask: 4 bytes (keys key0 + 4 g ..) of row qrow
 #pragma unroll
-  for (int j = 0; j < NQT; ++j) m_voff[j] = (uint32_t)(qrow[j] * N + 4 * g);
+  // a row that does not use the mask (row_open = 0, or no mask at all) reads beyond the descriptor's range: zeros = open
+  for (int j = 0; j < NQT; ++j) m_voff[j] = use_mask[j] ? (uint32_t)(qrow[j] * N + 4 * g) : 0x80000000u;
   const int row_bytes = E * 4;
 
   struct Frag {
@@ -367,17 +369,20 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
   // of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half.
   // Both results pass through an empty asm: this clang folds fmaxf(r[0], r[1]) of the builtin's pair into r[0]
   // (the v_max disappears from the ISA), which the opaque copies prevent.
+  // v_max_f32 without the canonicalising v_max x, x the compiler puts in front of fmaxf on values that come out of a bit
+  // cast (4 of the 6 vector instructions of a group maximum were those)
+  auto vmax = [](float x, float y) __attribute__((always_inline)) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  };
   auto group_max = [&](float x) __attribute__((always_inline)) {
     const uint32_t u = __builtin_bit_cast(uint32_t, x);
     const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    uint32_t a0 = a[0], a1 = a[1];
-    asm volatile("" : "+v"(a0), "+v"(a1));
-    const float y = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    const float y = vmax(__builtin_bit_cast(float, (uint32_t)a[0]), __builtin_bit_cast(float, (uint32_t)a[1]));
     const uint32_t w = __builtin_bit_cast(uint32_t, y);
     const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    uint32_t c0 = c[0], c1 = c[1];
-    asm volatile("" : "+v"(c0), "+v"(c1));
-    return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+    return vmax(__builtin_bit_cast(float, (uint32_t)c[0]), __builtin_bit_cast(float, (uint32_t)c[1]));
   };
   auto compute = [&](const Frag& f, bool live) __attribute__((always_inline)) {
     f32x4 s[NQT];
@@ -387,23 +392,40 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
 #pragma unroll
       for (int t = 0; t < DK; ++t) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.k[t], qf[j][t], s[j], 0, 0, 0);
     }
+    float tmax[NQT];
+    bool grow = false;
 #pragma unroll
     for (int j = 0; j < NQT; ++j) {
       uint32_t mb = f.mb[j];
       asm volatile("" : "+v"(mb));  // ordered after the fences: free, the mask tests of fb were placed in compute(fa) -- behind a vmcnt(0)
-      mb = use_mask[j] ? mb : 0u;
       mb = live ? mb : 0xffffffffu;
-      float tmax = NEG_INF;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[j][r] = ((mb >> (8 * r)) & 0xffu) != 0 ? NEG_INF : s[j][r];
-        tmax = fmaxf(tmax, s[j][r]);
+      for (int r = 0; r < 4; ++r) s[j][r] = ((mb >> (8 * r)) & 0xffu) != 0 ? NEG_INF : s[j][r];
+      tmax[j] = group_max(fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])));
+      grow |= tmax[j] > m[j] + kTau;
+    }
+    // Lazy rescale: m[j] is the reference the running (l, O) are scaled by, and it only has to stay within kTau
+    // (log2 units) of the true running maximum -- p <= 2^kTau, the quotient O / l is the same number.  The
+    // rescale of l and O (1 exp + 9 multiplies per query tile) runs only when some query's tile maximum exceeds
+    // its reference by more than that: the first live tile, and rarely afterwards.  ONE wave-uniform branch per
+    // key tile (one per query tile serialised the tiles' mask / max chains: 10 s_nop each).  fp32 MFMAs and vector
+    // instructions do not execute together on a SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on this kernel,
+    // profiles/r02_pmc_k2.txt), so every vector instruction removed is time removed.
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) {
+        const float m_new = fmaxf(m[j], tmax[j]);
+        const float m_s = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m[j] - m_s);
+        m[j] = m_new;
+        l[j] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[i][j] *= alpha;
       }
-      tmax = group_max(tmax);
-      const float m_new = fmaxf(m[j], tmax);
-      const float m_safe = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m[j] - m_safe);
-      m[j] = m_new;
+    }
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      const float m_safe = (m[j] == NEG_INF) ? 0.f : m[j];
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -411,9 +433,7 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_full_kernel(
         s[j][r] = p;
         psum += p;
       }
-      l[j] = l[j] * alpha + psum;
-#pragma unroll
-      for (int i = 0; i < DT; ++i) o[i][j] *= alpha;
+      l[j] += psum;
     }
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -676,7 +696,7 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
   const int n_tiles = ceil_div(N, 16);
   const int tps = ceil_div(n_tiles, n_splits);
   // query row tiles per workgroup: 2 (see xattn_splits; D = 64: at most 3 by register budget)
-  const int cap = (D == 64) ? 2 : tune_env("WM2F_K2_QTILES", 2);
+  const int cap = (D == 64) ? 2 : tune_env("WM2F_K2_QTILES", 7);
   const int q_tiles = ceil_div(Q, 16);
   const int q_chunks = ceil_div(q_tiles, cap);
   int nqt = ceil_div(q_tiles, q_chunks);
