@@ -120,6 +120,15 @@ int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const v
  *   from the (B, C, HW) map;  out (B, Q, HW) fp32;  C % 32 == 0, C <= 512. */
 int wm2f_mask_einsum_bf16_fwd(const void* emb, const void* pix_pixel_major, void* out, int B, int Q, int C,
                               int HW, void* stream);
+
+/* K3 backward under bf16 autocast (replaces grad.to(bfloat16) + two batched library GEMMs): grad_out is fp32 (the
+ * logits are), emb / pix and both gradients bf16 (round-to-nearest-even), accumulation fp32; g_emb summed in a fixed
+ * order.  Either output may be NULL.  `pix` is the NCHW tensor (B, C, HW), not the pixel-major copy.
+ * `workspace`: wm2f_mask_einsum_bf16_bwd_workspace(B, Q, C, HW) bytes.
+ *   C % 64 == 0, Q % 4 == 0, Q <= 112, HW % 8 == 0; other shapes: WM2F_EUNSUPPORTED */
+int64_t wm2f_mask_einsum_bf16_bwd_workspace(int B, int Q, int C, int HW);
+int wm2f_mask_einsum_bf16_bwd(const void* emb, const void* pix, const void* grad_out, void* g_emb, void* g_pix,
+                              void* workspace, int B, int Q, int C, int HW, void* stream);
 int wm2f_nchw_to_pixel_major_bf16(const void* src, void* dst, int B, int C, int HW, void* stream);
 
 /* ---- K3: mask einsum --------------------------------------------------------------------
@@ -137,6 +146,16 @@ int wm2f_mask_einsum_fwd(const void* emb, const void* pix, void* out, int B, int
  *   C % 16 == 0, HW % 4 == 0 */
 int wm2f_mask_einsum_attn_mask_fwd(const void* emb, const void* pix, void* mask, void* row_open, int B, int Q, int C,
                                    int HW, int dtype, void* stream);
+
+/* K3 backward (HF:2046 under autograd; replaces the two batched library GEMMs autograd derives from the einsum):
+ *   g_pix[b][c][p] = sum_q emb[b][q][c] * grad_out[b][q][p]      g_emb[b][q][c] = sum_p grad_out[b][q][p] * pix[b][c][p]
+ * Either output may be NULL (not wanted).  g_emb is summed in a fixed order (pixel ranges to a workspace, then in range
+ * order): no atomics, run-to-run identical.  `workspace`: wm2f_mask_einsum_bwd_workspace(B, Q, C, HW) bytes.
+ *   emb (B, Q, C)   pix (B, C, HW)   grad_out (B, Q, HW)   g_emb (B, Q, C)   g_pix (B, C, HW)   all fp32
+ *   C % 64 == 0, Q % 4 == 0, HW % 4 == 0; other shapes: WM2F_EUNSUPPORTED */
+int64_t wm2f_mask_einsum_bwd_workspace(int B, int Q, int C, int HW);
+int wm2f_mask_einsum_bwd(const void* emb, const void* pix, const void* grad_out, void* g_emb, void* g_pix,
+                         void* workspace, int B, int Q, int C, int HW, int dtype, void* stream);
 
 /* ---- attention-mask build ----------------------------------------------------------------
  * Replaces HF:2048-2054 (bilinear resize, sigmoid, < 0.5) WITHOUT the x num_heads replication,

@@ -348,31 +348,65 @@ def test_k3_bf16(ops, B, Q, C, H, W):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-4)
 
 
-def test_k3_bf16_backward(ops):
+@pytest.mark.parametrize("B,Q,C,H,W", [(2, 20, 64, 8, 12),      # 2 query steps, the second with 3 lane groups empty; 1.5 strips
+                                       (1, 100, 256, 64, 64),   # the production shape at a small map
+                                       (2, 112, 128, 16, 40),   # all 7 query steps full, 640 pixels = 10 strips, 2 channel groups
+                                       (3, 36, 64, 24, 31),     # pixel ranges that end inside a 32-pixel step (744 pixels)
+                                       (1, 200, 64, 8, 8),      # more than 112 queries: two library GEMMs
+                                       (1, 12, 64, 2, 2)])      # HW % 8 != 0: two library GEMMs
+def test_k3_bf16_backward(ops, B, Q, C, H, W):
+    """bf16-autocast backward of the einsum: against the fp64 products of the SAME bf16-rounded operands (grad rounded to
+    bf16 as torch's .to(bfloat16) does), so that only the fp32 accumulation order and the final rounding of the bf16
+    outputs differ; g_emb run-to-run identical."""
     g = torch.Generator().manual_seed(32)
-    B, Q, C, H, W = 2, 20, 64, 8, 12
     emb = torch.randn(B, Q, C, generator=g).to(torch.bfloat16)
     pix = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16)
     go = torch.randn(B, Q, H, W, generator=g)
     e, p = dev(emb).requires_grad_(True), dev(pix).requires_grad_(True)
-    out = ops.mask_einsum_bf16(e, p, ops.nchw_to_pixel_major_bf16(p))
-    out.backward(dev(go))
-    er, pr = emb.float().requires_grad_(True), pix.float().requires_grad_(True)
-    torch.einsum("bqc,bchw->bqhw", er, pr).backward(go)
-    torch.testing.assert_close(e.grad.float().cpu(), er.grad, rtol=2e-2, atol=2e-1)  # bf16 GEMMs with bf16 outputs
-    torch.testing.assert_close(p.grad.float().cpu(), pr.grad, rtol=2e-2, atol=2e-1)
+    out = ops.mask_einsum_bf16(e, p, ops.nchw_to_pixel_major_bf16(p)) if Q <= 112 else None
+    gob = go.to(torch.bfloat16).double()
+    ge_ref = torch.einsum("bqhw,bchw->bqc", gob, pix.double())
+    gp_ref = torch.einsum("bqc,bqhw->bchw", emb.double(), gob)
+    if out is not None:
+        out.backward(dev(go))
+        ge, gp = e.grad, p.grad
+    else:
+        ge, gp = ops.mask_einsum_bf16_bwd(dev(emb), dev(pix), dev(go))
+    assert ge.dtype == torch.bfloat16 and gp.dtype == torch.bfloat16 and gp.shape == pix.shape
+    # one bf16 rounding of the result (2^-9 relative) on top of an fp32 sum
+    torch.testing.assert_close(ge.double().cpu(), ge_ref, rtol=4e-3, atol=4e-3 * float(ge_ref.abs().max()) / 16)
+    torch.testing.assert_close(gp.double().cpu(), gp_ref, rtol=4e-3, atol=4e-3 * float(gp_ref.abs().max()) / 16)
+    ge2, gp2 = ops.mask_einsum_bf16_bwd(dev(emb), dev(pix), dev(go))
+    assert torch.equal(ge2, ge) and torch.equal(gp2, gp)
+    assert ops.mask_einsum_bf16_bwd_applies(Q, C, H * W) == (Q <= 112 and (H * W) % 8 == 0)
 
 
-def test_k3_backward(ops):
+@pytest.mark.parametrize("B,Q,C,H,W", [(2, 20, 64, 8, 12),      # one row tile + 4, one super-step of queries with 3 lane groups empty
+                                       (1, 100, 256, 64, 64),   # the production shape at a small map: 4 channel chunks, 7 query tiles
+                                       (2, 200, 256, 20, 36),   # two query chunks (config 4), pixel count not a multiple of 16 or 64
+                                       (1, 16, 128, 2, 2),      # a single 4-pixel step, queries a whole super-step
+                                       (3, 36, 64, 50, 50),     # pixel ranges that end inside a 16-pixel step
+                                       (1, 10, 32, 4, 4)])      # outside the kernels' shapes (C % 64, Q % 4): two library GEMMs
+def test_k3_backward(ops, B, Q, C, H, W):
+    """Both gradients of the einsum (HF:2046 under autograd) from wm2f_mask_einsum_bwd against fp64 autograd of the same
+    einsum, and g_emb run-to-run identical (fixed summation order, no atomics)."""
     g = torch.Generator().manual_seed(6)
-    emb, pix = torch.randn(2, 20, 64, generator=g), torch.randn(2, 64, 8, 12, generator=g)
-    go = torch.randn(2, 20, 8, 12, generator=g)
-    e0, p0 = emb.clone().requires_grad_(), pix.clone().requires_grad_()
-    torch.einsum("bqc,bchw->bqhw", e0, p0).backward(go)
+    emb, pix = torch.randn(B, Q, C, generator=g), torch.randn(B, C, H, W, generator=g)
+    go = torch.randn(B, Q, H, W, generator=g)
+    e0, p0 = emb.double().requires_grad_(), pix.double().requires_grad_()
+    torch.einsum("bqc,bchw->bqhw", e0, p0).backward(go.double())
+    assert ops.mask_einsum_bwd_applies(Q, C, H * W) == (C % 64 == 0 and Q % 4 == 0)
     e1, p1 = dev(emb).requires_grad_(), dev(pix).requires_grad_()
     ops.mask_einsum(e1, p1).backward(dev(go))
-    torch.testing.assert_close(e1.grad.cpu(), e0.grad, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(p1.grad.cpu(), p0.grad, rtol=1e-4, atol=1e-4)
+    # |g_emb| ~ sqrt(HW), |g_pix| ~ sqrt(Q): fp32 sums of that many products
+    torch.testing.assert_close(e1.grad.cpu().double(), e0.grad, rtol=1e-4, atol=2e-5 * (H * W) ** 0.5 + 1e-4)
+    torch.testing.assert_close(p1.grad.cpu().double(), p0.grad, rtol=1e-4, atol=1e-4)
+    ge, gp = ops.mask_einsum_bwd(dev(emb), dev(pix), dev(go))
+    assert torch.equal(ge, e1.grad) and torch.equal(gp, p1.grad)
+    only_e, none_p = ops.mask_einsum_bwd(dev(emb), dev(pix), dev(go), True, False)
+    assert none_p is None and torch.equal(only_e, ge)
+    none_e, only_p = ops.mask_einsum_bwd(dev(emb), dev(pix), dev(go), False, True)
+    assert none_e is None and torch.equal(only_p, gp)
 
 
 # ----------------------------------------------------------------------------------------- K2

@@ -226,6 +226,37 @@ def main():
             r = timeit(lambda: ops.resize_bilinear(pix, hw), a.iters)
             r.update(bytes=4 * (pix.numel() + B * 256 * hw[0] * hw[1]))
             res[f"resize_mask_features_to_{hw[0]}"] = r
+    if "k3g" in only:  # K3 backward: hand-written pair against the two batched library GEMMs autograd derives
+        emb = torch.randn(B, Q, 256, device=dev)
+        pix = torch.randn(B, 256, 256, 256, device=dev)
+        go = torch.randn(B, Q, 256, 256, device=dev)
+        flop = 2 * B * Q * 256 * 65536
+        for name, we, wp in (("both", True, True), ("g_emb", True, False), ("g_pix", False, True)):
+            r = timeit(lambda: ops.mask_einsum_bwd(emb, pix, go, we, wp), a.iters)
+            r.update(flop=flop * (we + wp), TFLOPs=flop * (we + wp) / r["med_us"] / 1e6)
+            res[f"k3_backward_{name}"] = r
+        gof, pf = go.reshape(B, Q, -1), pix.reshape(B, 256, -1)
+        r = timeit(lambda: torch.bmm(gof, pf.transpose(1, 2)), a.iters)
+        r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6)
+        res["library_bmm_g_emb"] = r
+        r = timeit(lambda: torch.bmm(emb.transpose(1, 2), gof), a.iters)
+        r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6)
+        res["library_bmm_g_pix"] = r
+    if "k3gb" in only:  # K3 backward under bf16 autocast: hand-written pair against .to(bf16) + two batched library GEMMs
+        emb = torch.randn(B, Q, 256, device=dev).to(torch.bfloat16)
+        pix = torch.randn(B, 256, 256, 256, device=dev).to(torch.bfloat16)
+        pix_t = ops.nchw_to_pixel_major_bf16(pix)
+        go = torch.randn(B, Q, 256, 256, device=dev)
+        for name, we, wp in (("both", True, True), ("g_emb", True, False), ("g_pix", False, True)):
+            r = timeit(lambda: ops.mask_einsum_bf16_bwd(emb, pix, go, we, wp), a.iters)
+            nb = go.numel() * 4 * (we + wp) + (pix.numel() * 2 if we else 0) + (pix.numel() * 2 if wp else 0)
+            r.update(bytes=nb, GBps=nb / r["med_us"] / 1e3)
+            res[f"k3_bf16_backward_{name}"] = r
+
+        def lib():
+            gb = go.reshape(B, Q, -1).to(torch.bfloat16)
+            return torch.bmm(gb, pix_t), torch.bmm(emb.transpose(1, 2), gb)
+        res["library_bf16_cast_and_two_bmm"] = timeit(lib, a.iters)
     if "k3b" in only:  # K3 on the bf16 matrix cores (bf16 autocast path): HBM-bound
         emb = torch.randn(B, Q, 256, device=dev).to(torch.bfloat16)
         pix = torch.randn(B, 256, 256, 256, device=dev).to(torch.bfloat16)

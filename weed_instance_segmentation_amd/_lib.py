@@ -44,6 +44,10 @@ SIGNATURES = {
     "wm2f_nchw_to_pixel_major_bf16": (c_int, [_P, _P, _I, _I, _I, _P]),
     "wm2f_mask_einsum_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_mask_einsum_attn_mask_fwd": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm2f_mask_einsum_bf16_bwd_workspace": (c_int64, [_I, _I, _I, _I]),
+    "wm2f_mask_einsum_bf16_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "wm2f_mask_einsum_bwd_workspace": (c_int64, [_I, _I, _I, _I]),
+    "wm2f_mask_einsum_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_masked_xattn_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_masked_xattn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

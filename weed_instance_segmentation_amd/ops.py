@@ -240,13 +240,36 @@ class _MaskEinsum(torch.autograd.Function):
     @staticmethod
     @_amp_bwd
     def backward(ctx, grad_out):
-        # Two plain batched GEMMs (library GEMM: rocBLAS / hipBLASLt through torch.bmm).
         emb, pix = ctx.saved_tensors
-        B, Q, C = emb.shape
-        go = grad_out.reshape(B, Q, -1)
-        g_emb = torch.bmm(go, pix.reshape(B, C, -1).transpose(1, 2)) if ctx.needs_input_grad[0] else None
-        g_pix = torch.bmm(emb.transpose(1, 2), go).view_as(pix) if ctx.needs_input_grad[1] else None
+        g_emb, g_pix = mask_einsum_bwd(emb, pix, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return g_emb, g_pix, None
+
+
+def mask_einsum_bwd_applies(Q: int, C: int, HW: int) -> bool:
+    """Shapes the hand-written K3 backward covers (wm2f.h); others take two batched library GEMMs."""
+    return C % 64 == 0 and Q % 4 == 0 and HW % 4 == 0 and (C + 16) * HW * 4 < 2 ** 31 and (Q + 16) * HW * 4 < 2 ** 31
+
+
+def mask_einsum_bwd(emb, pix, grad_out, want_emb=True, want_pix=True):
+    """K3 backward: g_emb (B,Q,C) = grad x pix^T, g_pix (B,C,H,W) = emb^T x grad (wm2f_mask_einsum_bwd; deterministic)."""
+    B, Q, C = emb.shape
+    HW = int(pix.shape[2]) * int(pix.shape[3])
+    if not mask_einsum_bwd_applies(Q, C, HW):
+        go = grad_out.reshape(B, Q, -1)
+        g_emb = torch.bmm(go, pix.reshape(B, C, -1).transpose(1, 2)) if want_emb else None
+        g_pix = torch.bmm(emb.transpose(1, 2), go).view_as(pix) if want_pix else None
+        return g_emb, g_pix
+    emb, pix, go = _req(emb, "emb"), _req(pix, "pix"), _req(grad_out.contiguous(), "grad_out")
+    g_emb = torch.empty_like(emb) if want_emb else None
+    g_pix = torch.empty_like(pix) if want_pix else None
+    if not (want_emb or want_pix):
+        return None, None
+    with torch.cuda.device(emb.device):
+        ws = torch.empty(int(load().wm2f_mask_einsum_bwd_workspace(B, Q, C, HW)), device=emb.device, dtype=torch.uint8)
+        check(_timed("mask_einsum_bwd", emb, lambda: load().wm2f_mask_einsum_bwd(
+            _p(emb), _p(pix), _p(go), _p(g_emb) if want_emb else None, _p(g_pix) if want_pix else None, _p(ws),
+            B, Q, C, HW, WM2F_F32, _stream(emb))), "wm2f_mask_einsum_bwd")
+    return g_emb, g_pix
 
 
 def mask_einsum(emb: torch.Tensor, pix: torch.Tensor, tag: str | None = None) -> torch.Tensor:
@@ -287,20 +310,49 @@ class _MaskEinsumBf16(torch.autograd.Function):
                     _p(e), _p(pix_t), _p(oc), B, q1 - q0, C, Hh * Ww, _stream(emb))), "wm2f_mask_einsum_bf16_fwd")
                 if oc is not o:
                     o.copy_(oc)
-        ctx.save_for_backward(emb, pix_t)
-        ctx.pix_shape = tuple(pix.shape)
+        # `pix` (the NCHW tensor) is the backward's right operand: contiguous along the pixel contraction.  It is an input
+        # of the forward and alive anyway; pix_t is kept only for shapes the backward kernels do not cover.
+        ctx.save_for_backward(emb, pix_t, pix)
         return out
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, grad_out):
-        # Two plain batched GEMMs in bf16 (library GEMM through torch.bmm), as for the fp32 kernel.
-        emb, pix_t = ctx.saved_tensors
-        B, Q, C = emb.shape
-        go = grad_out.reshape(B, Q, -1).to(torch.bfloat16)
-        g_emb = torch.bmm(go, pix_t) if ctx.needs_input_grad[0] else None
-        g_pix = torch.bmm(emb.transpose(1, 2), go).view(ctx.pix_shape) if ctx.needs_input_grad[1] else None
+        emb, pix_t, pix = ctx.saved_tensors
+        g_emb, g_pix = mask_einsum_bf16_bwd(emb, pix, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1], pix_t)
         return g_emb, g_pix, None
+
+
+def mask_einsum_bf16_bwd_applies(Q: int, C: int, HW: int) -> bool:
+    """Shapes the hand-written bf16 K3 backward covers (wm2f.h); others take two batched library GEMMs."""
+    return C % 64 == 0 and Q % 4 == 0 and Q <= 112 and HW % 8 == 0 and (C + 16) * HW * 2 < 2 ** 31 and (Q + 16) * HW * 4 < 2 ** 31
+
+
+def mask_einsum_bf16_bwd(emb, pix, grad_out, want_emb=True, want_pix=True, pix_t=None):
+    """K3 backward under bf16 autocast: emb (B,Q,C) bf16, pix (B,C,H,W) bf16, grad_out (B,Q,H,W) fp32 -> g_emb, g_pix bf16
+    (wm2f_mask_einsum_bf16_bwd: grad rounded to bf16 in registers, fp32 accumulation, deterministic)."""
+    B, Q, C = emb.shape
+    HW = int(pix.shape[2]) * int(pix.shape[3])
+    if not (want_emb or want_pix):
+        return None, None
+    if not mask_einsum_bf16_bwd_applies(Q, C, HW) or pix.dtype != torch.bfloat16 or not pix.is_contiguous():
+        go = grad_out.reshape(B, Q, -1).to(torch.bfloat16)
+        if pix_t is None:
+            pix_t = pix.reshape(B, C, HW).transpose(1, 2).to(torch.bfloat16)
+        g_emb = torch.bmm(go, pix_t) if want_emb else None
+        g_pix = torch.bmm(emb.transpose(1, 2), go).view(pix.shape).to(pix.dtype) if want_pix else None
+        return g_emb, g_pix
+    emb = _req(emb, "emb", torch.bfloat16)
+    pix = _req(pix, "pix", torch.bfloat16)
+    go = _req(grad_out.contiguous(), "grad_out")
+    g_emb = torch.empty_like(emb) if want_emb else None
+    g_pix = torch.empty_like(pix) if want_pix else None
+    with torch.cuda.device(emb.device):
+        ws = torch.empty(int(load().wm2f_mask_einsum_bf16_bwd_workspace(B, Q, C, HW)), device=emb.device, dtype=torch.uint8)
+        check(_timed("mask_einsum_bf16_bwd", emb, lambda: load().wm2f_mask_einsum_bf16_bwd(
+            _p(emb), _p(pix), _p(go), _p(g_emb) if want_emb else None, _p(g_pix) if want_pix else None, _p(ws),
+            B, Q, C, HW, _stream(emb))), "wm2f_mask_einsum_bf16_bwd")
+    return g_emb, g_pix
 
 
 def mask_einsum_bf16(emb: torch.Tensor, pix: torch.Tensor, pix_t: torch.Tensor) -> torch.Tensor:
