@@ -63,6 +63,20 @@ int wm2f_msdeform_bwd(const void* value, const void* loc, const void* attn_w, co
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
                       int dtype, void* stream);
 
+/* K1 backward with run-to-run identical results (same arguments and outputs as wm2f_msdeform_bwd plus a workspace of
+ * wm2f_msdeform_bwd_det_workspace(level_hw, B, S, heads, D, L) bytes; 0 = not built for these levels).  No float atomics:
+ * every tile stores its LDS window into its own slab of the workspace and a second kernel sums, per grad_value element,
+ * the windows covering it in a fixed tile order; the rare points outside a window are added as integers into an int64
+ * fixed-point image (unit 2^-44 of the largest |grad_out| of the image and head; overflow-free for S < 2^17).
+ * grad_loc / grad_attn_w never had a scatter.  `grad_value` need not be cleared by the caller.
+ * Built for the LDS-window backward only (head_dim 32, 4 points, Q == S, levels that fit its windows); otherwise
+ * WM2F_EUNSUPPORTED. */
+int64_t wm2f_msdeform_bwd_det_workspace(const int32_t* level_hw, int B, int S, int heads, int D, int L);
+int wm2f_msdeform_bwd_det(const void* value, const void* loc, const void* attn_w, const void* grad_out,
+                          void* grad_value, void* grad_loc, void* grad_attn_w, void* workspace,
+                          const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
+                          void* stream);
+
 /* K1 with the module prologue fused (HF:983-1002): softmax over the L*P logits and
  * loc = ref + offset / (W_l, H_l) are computed in-kernel.
  *   offsets (B, Q, heads, L, P, 2)  raw sampling_offsets output

@@ -242,6 +242,52 @@ def test_k1_backward_local_offsets(ops, shapes, B):
     torch.testing.assert_close(l1.grad.cpu(), l0.grad, rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("shapes,B,scale", [([(8, 8), (16, 16), (32, 32)], 2, 1.0), ([(5, 7), (10, 14), (20, 28)], 1, 1e-6),
+                                            ([(12, 20), (24, 40)], 2, 3e4)])
+def test_k1_backward_deterministic_form(ops, shapes, B, scale):
+    """wm2f_msdeform_bwd_det: the grad_value scatter as integer adds in one fixed-point unit per (image, head).  Against
+    the oracle's autograd like the float-atomic form (gradient magnitudes from 1e-6 to 3e4: the unit follows the
+    largest |grad_out|), bit-identical from run to run and under a different stream of other work, with one image's
+    gradients a million times smaller than the other's, and through torch's deterministic-algorithms switch."""
+    H, D, L, P = 8, 32, len(shapes), 4
+    g = torch.Generator().manual_seed(17)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * 2.5
+    off[0, 5, 1, 0, 2] = torch.tensor([-30.0, 25.0])  # out of every window: the straight-to-memory adds
+    off[0, 9, 2, L - 1, 1] = torch.tensor([14.0, -9.0])
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
+    loc = (ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+    w = torch.softmax(torch.randn(B, S, H, L * P, generator=g), -1).view(B, S, H, L, P).contiguous()
+    go = torch.randn(B, S, H * D, generator=g) * scale
+    if B > 1:
+        go[1] *= 1e-6
+    v0, l0, w0 = value.clone().requires_grad_(), loc.clone().requires_grad_(), w.clone().requires_grad_()
+    O.msdeform_attn_core(v0, shapes, l0, w0).backward(go)
+    gv, gl, gw = ops.ms_deform_attn_bwd(dev(value), shapes, dev(loc), dev(w), dev(go), deterministic=True)
+    for b in range(B):
+        ref = v0.grad[b]
+        torch.testing.assert_close(gv[b].cpu(), ref, rtol=1e-4, atol=2e-5 * float(go[b].abs().max()))
+    torch.testing.assert_close(gw.cpu(), w0.grad, rtol=1e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(gl.cpu(), l0.grad, rtol=1e-3, atol=2e-4 * scale)
+    for _ in range(3):
+        junk = torch.randn(1 << 20, device=gv.device).sin_()  # other work in flight
+        gv2, gl2, gw2 = ops.ms_deform_attn_bwd(dev(value), shapes, dev(loc), dev(w), dev(go), deterministic=True)
+        assert torch.equal(gv2, gv) and torch.equal(gl2, gl) and torch.equal(gw2, gw)
+        del junk
+    prev = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        v1, l1, w1 = dev(value).requires_grad_(), dev(loc).requires_grad_(), dev(w).requires_grad_()
+        ops.ms_deform_attn(v1, shapes, l1, w1).backward(dev(go))
+        assert torch.equal(v1.grad, gv)
+        with pytest.raises(RuntimeError):  # no fixed-point form for head_dim 16: refused under the switch, not silently float atomics
+            ops.ms_deform_attn_bwd(dev(value[..., :16].contiguous()), shapes, dev(loc), dev(w), dev(go[..., :H * 16].contiguous()))
+    finally:
+        torch.use_deterministic_algorithms(prev)
+
+
 # ----------------------------------------------------------------------------------------- K3
 def test_k3_golden(ops):
     g = load_golden("k3_mask_predictor.npz")

@@ -123,6 +123,8 @@ def main():
                 o.backward(go)
                 vv.grad = ll.grad = ww_.grad = None
             res["k1_fwd_plus_bwd"] = timeit(fb, a.iters)
+            res["k1_bwd_float_atomics"] = timeit(lambda: ops.ms_deform_attn_bwd(value, shapes, loc, aw, go, deterministic=False), a.iters)
+            res["k1_bwd_deterministic"] = timeit(lambda: ops.ms_deform_attn_bwd(value, shapes, loc, aw, go, deterministic=True), a.iters)
         if any(k in only for k in ("k1t", "k1q", "k1s", "k1h")):  # one variant only, for PMC runs (LDS-window / phased quad / streaming half-head / full-head)
             vv_ = 2 if "k1t" in only else (3 if "k1q" in only else (8 if "k1h" in only else 4))  # k1h: half-head form
             r = timeit(lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=vv_, margin=4), a.iters)

@@ -257,7 +257,8 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
 // msdeform_tiled_bwd.hip
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
                      void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
-                     int margin, void* stream, const char* who, bool* handled);
+                     int margin, void* stream, const char* who, bool* handled, void* det_ws);
+int64_t tiled_bwd_det_workspace(const int32_t* level_hw, int B, int S, int heads, int L);
 
 struct LaunchGeom {
   int64_t n_pairs;
@@ -464,7 +465,7 @@ extern "C" int wm2f_msdeform_bwd(const void* value, const void* loc, const void*
   if (D == 32) {  // LDS-window backward: the scatter is absorbed on chip
     bool handled = false;
     if (int rc = launch_tiled_bwd(value, loc, attn_w, grad_out, grad_value, grad_loc, grad_attn_w, level_hw, B, S, Q,
-                                  heads, L, P, 4, stream, who, &handled))
+                                  heads, L, P, 4, stream, who, &handled, nullptr))
       return rc;
     if (handled) return WM2F_OK;
   }
@@ -483,5 +484,35 @@ extern "C" int wm2f_msdeform_bwd(const void* value, const void* loc, const void*
   }
 #undef WM2F_LAUNCH_BWD
   WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int64_t wm2f_msdeform_bwd_det_workspace(const int32_t* level_hw, int B, int S, int heads, int D, int L) {
+  if (!level_hw || B <= 0 || S <= 0 || heads <= 0 || D != 32) return 0;
+  return tiled_bwd_det_workspace(level_hw, B, S, heads, L);
+}
+
+extern "C" int wm2f_msdeform_bwd_det(const void* value, const void* loc, const void* attn_w, const void* grad_out,
+                                     void* grad_value, void* grad_loc, void* grad_attn_w, void* workspace,
+                                     const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
+                                     void* stream) {
+  const char* who = "wm2f_msdeform_bwd_det";
+  WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
+  WM2F_REQUIRE(value && loc && attn_w && grad_out && grad_value && grad_loc && grad_attn_w && level_hw && workspace,
+               "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && S > 0 && Q > 0 && heads > 0 && P > 0, "%s: non-positive size", who);
+  LevelInfo lv;
+  if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  bool handled = false;
+  if (D == 32 && S < (1 << 17)) {
+    if (int rc = launch_tiled_bwd(value, loc, attn_w, grad_out, grad_value, grad_loc, grad_attn_w, level_hw, B, S, Q, heads, L,
+                                  P, 4, stream, who, &handled, workspace))
+      return rc;
+  }
+  if (!handled) {
+    set_error("%s: only the LDS-window backward has the fixed-point form (head_dim 32, 4 points, self-attention Q == S, "
+              "levels that fit its windows, S < 2^17)", who);
+    return WM2F_EUNSUPPORTED;
+  }
   return WM2F_OK;
 }

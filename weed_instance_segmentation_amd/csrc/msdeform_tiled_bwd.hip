@@ -198,10 +198,23 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
 // wave then walks the points with those values as scalars (v_readlane), and every atomic instruction
 // adds two contiguous 128-B rows: lanes 0-31 = the 32 channels of the left corner, lanes 32-63 = the
 // right corner.  No redundant coordinate arithmetic, at most 2-way LDS bank conflicts.
-template <int NL, int P>
+//
+// DET (wm2f_msdeform_bwd_det): run-to-run identical grad_value.  The window sums are already order-independent
+// (integer LDS adds); what was not is the order in which overlapping windows (and the rare out-of-window points) reach
+// memory with FLOAT atomics.  Here a tile does not add its window to grad_value at all: it STORES the whole window (plain
+// coalesced float4 stores, converted with the tile's scale) into its own slab of a staging buffer, and a second kernel
+// (units_gather_kernel) sums, for every grad_value element, the windows that cover it in a fixed tile order.  The rare
+// points whose footprint leaves the window are added as INTEGERS into an int64 image in one fixed-point unit per
+// (image, head): unit = 2^(E - 44), E = exponent of max|grad_out| over that image and head (a pre-pass); any element's
+// true sum is below S * 2^(E + 1) (each of the S queries adds at most its grad_out times weights that sum to <= 1),
+// i.e. below 2^62 units for S < 2^17 -- no overflow, and integer addition commutes.  (All adds as 64-bit integer
+// atomics were tried first: 7.5 ms against 2.8 ms for the float atomics -- the 64-bit atomic rate; the staging form
+// moves 0.6 GB each way as plain traffic instead.)
+template <int NL, int P, bool DET>
 __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn_w, const float* __restrict__ grad_out,
-    float* __restrict__ grad_value, TileGeom g, int S, int Q, int heads, int n_logical, int per_xcd) {
+    float* __restrict__ grad_value, float* __restrict__ staging, long long* __restrict__ acc64, const int* __restrict__ emax_bits,
+    TileGeom g, int S, int Q, int heads, int n_logical, int per_xcd) {
   constexpr int D = 32, kWaves = kBwdThreads / kWave, NP = NL * P;
   static_assert(NP <= 64, "one lane per sampling point");
   extern __shared__ __attribute__((aligned(16))) float4 win[];
@@ -237,6 +250,16 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
   for (int w = 0; w < kBwdThreads / kWave; ++w) gmax = fmaxf(gmax, ch_max[w][ch]);
   const float fx_scale = gmax > 0.f ? 4194304.f / gmax : 0.f;  // 2^22 / max
   const float fx_inv = gmax > 0.f ? gmax * (1.f / 4194304.f) : 0.f;
+  float det_unit_inv = 0.f;  // DET: 2^(44 - E), a float -> units of the spill image
+  long long* acc_b = nullptr;
+  __shared__ float ch_inv[32];
+  if (DET) {
+    int E = ((emax_bits[c.b * heads + c.h] >> 23) & 0xff) - 127;
+    if (E < -80) E = -80;
+    det_unit_inv = __int_as_float((44 - E + 127) << 23);
+    acc_b = acc64 + ((int64_t)c.b * S * heads + c.h) * D;
+    if (tid < 32) ch_inv[tid] = fx_inv;  // lane = channel for tid < 32
+  }
   int* wini = reinterpret_cast<int*>(win);
 
   // this lane's point (lanes >= NP idle in the per-point phase): level constants
@@ -296,6 +319,11 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
       if (f & 16) {  // whole footprint inside the window: LDS accumulation
         if (ok_t) atomicAdd(wini + li + hs * 32 + ch, __float2int_rn(wt * gofs));
         if (ok_b) atomicAdd(wini + li + (wwp + hs) * 32 + ch, __float2int_rn(wb * gofs));
+      } else if (DET) {  // rare: straight to memory, in units
+        if (ok_t) atomicAdd(reinterpret_cast<unsigned long long*>(acc_b + (int64_t)(gi + hs) * row_stride + ch),
+                            (unsigned long long)__float2ll_rn(wt * gof * det_unit_inv));
+        if (ok_b) atomicAdd(reinterpret_cast<unsigned long long*>(acc_b + (int64_t)(gi + Wlp + hs) * row_stride + ch),
+                            (unsigned long long)__float2ll_rn(wb * gof * det_unit_inv));
       } else {  // rare: straight to memory
         if (ok_t) atomicAdd(gvb + (int64_t)(gi + hs) * row_stride + ch, wt * gof);
         if (ok_b) atomicAdd(gvb + (int64_t)(gi + Wlp + hs) * row_stride + ch, wb * gof);
@@ -303,6 +331,16 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
     }
   }
   __syncthreads();
+  if (DET) {  // the whole window, converted, into this tile's slab (float4 i holds channels 4 (i % 8) ..)
+    float4* slab = reinterpret_cast<float4*>(staging) + (int64_t)id * g.lv_tab_off4;
+    const int4* wi4 = reinterpret_cast<const int4*>(win);
+    for (int i = tid; i < g.lv_tab_off4; i += kBwdThreads) {
+      const int4 v = wi4[i];
+      const float4 sc = *reinterpret_cast<const float4*>(ch_inv + 4 * (i & 7));
+      slab[i] = make_float4((float)v.x * sc.x, (float)v.y * sc.y, (float)v.z * sc.z, (float)v.w * sc.w);
+    }
+    return;
+  }
   // flush: one lane per channel, 32 lanes per pixel -> every atomic wave-instruction is two whole 128-B rows
   const int pslot = tid >> 5;
 #pragma unroll
@@ -322,9 +360,98 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
   }
 }
 
+// max |grad_out| per (image, head) as float bits (non-negative floats order like their bit patterns): blockDim = heads * D
+// threads, one (head, channel) each, striding over the queries of one image chunk.
+__global__ void absmax_image_head_kernel(const float* __restrict__ go, int* __restrict__ emax_bits, int Q, int heads, int D, int rows_per_block) {
+  const int b = blockIdx.y, t = threadIdx.x, row = heads * D;
+  const int q0 = blockIdx.x * rows_per_block, q1 = min(Q, q0 + rows_per_block);
+  float m = 0.f;
+  for (int q = q0; q < q1; ++q) m = fmaxf(m, fabsf(go[((int64_t)b * Q + q) * row + t]));
+  // D = 32: the head's channels are the 32 lanes of a half wave -- one atomic per (workgroup, head); one per thread
+  // (all on B * heads words) cost 4.1 ms
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((t & 31) == 0) atomicMax(emax_bits + b * heads + t / D, __float_as_int(m));
+}
+
+// grad_value element (b, token, head, channel) = sum over the tiles whose window covers the token's pixel, in (ty, tx)
+// order, of that window's value, plus the out-of-window spill in units.  One workgroup per token: thread = (head, channel).
+// The covering tiles are the same for the whole workgroup: the first wave tests the <= 64 candidate tiles (one per lane,
+// the integer divisions of the window origins happen once per token, not once per element) and compacts the hits, in
+// candidate order, into LDS.
+template <int NL>
+__global__ void units_gather_kernel(const float* __restrict__ staging, const long long* __restrict__ acc, const int* __restrict__ emax_bits,
+                                    float* __restrict__ out, TileGeom g, int S, int heads, int reach) {
+  const int tok = blockIdx.x, b = blockIdx.y, t = threadIdx.x;  // blockDim = heads * 32
+  const int h = t >> 5, ch = t & 31;
+  __shared__ int n_cov;
+  __shared__ int cov_tile[64], cov_woff[64];
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < NL; ++k) l += (tok >= g.start[k]) ? 1 : 0;
+  int off4 = g.lds_off4[0];
+#pragma unroll
+  for (int k = 1; k < NL; ++k)
+    if (l == k) off4 = g.lds_off4[k];
+  if (t < 64) {
+    int Wl = g.w[0], Hl = g.h[0], ww = g.win_w[0], wh = g.win_h[0], st = g.start[0];
+#pragma unroll
+    for (int k = 1; k < NL; ++k)
+      if (l == k) { Wl = g.w[k]; Hl = g.h[k]; ww = g.win_w[k]; wh = g.win_h[k]; st = g.start[k]; }
+    const int y = (tok - st) / Wl, x = (tok - st) - y * Wl;
+    const int Wf = g.w[g.fine], Hf = g.h[g.fine];
+    // tile whose region holds the pixel centre, then every tile within `reach` of it (host: margin / region + 2)
+    const int txc = min(g.tiles_x - 1, (int)(((int64_t)(2 * x + 1) * Wf) / ((int64_t)2 * g.F * Wl)));
+    const int tyc = min(g.tiles_y - 1, (int)(((int64_t)(2 * y + 1) * Hf) / ((int64_t)2 * g.F * Hl)));
+    const int side = 2 * reach + 1;  // host: side * side <= 64
+    const int ty = tyc - reach + t / side, tx = txc - reach + t % side;
+    bool hit = false;
+    int woff = 0;
+    if (t < side * side && ty >= 0 && ty < g.tiles_y && tx >= 0 && tx < g.tiles_x) {
+      const int wy = y - (floor_div_i(2 * ty * g.F * Hl - Hf, 2 * Hf) - g.M);
+      const int wx = x - (floor_div_i(2 * tx * g.F * Wl - Wf, 2 * Wf) - g.M);
+      hit = (unsigned)wy < (unsigned)wh && (unsigned)wx < (unsigned)ww;
+      woff = (wy * ww + wx) * 32;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if (hit) {
+      const int pos = __builtin_popcountll(m & ((1ull << t) - 1ull));
+      cov_tile[pos] = ty * g.tiles_x + tx;
+      cov_woff[pos] = woff;
+    }
+    if (t == 0) n_cov = __builtin_popcountll(m);
+  }
+  __syncthreads();
+  const int n_tiles = g.tiles_x * g.tiles_y;
+  float sum = 0.f;
+  for (int k = 0; k < n_cov; ++k) {
+    const int64_t id = ((int64_t)b * n_tiles + cov_tile[k]) * heads + h;
+    sum += staging[(id * g.lv_tab_off4 + off4) * 4 + cov_woff[k] + ch];
+  }
+  const int64_t i = (((int64_t)b * S + tok) * heads + h) * 32 + ch;
+  const long long sp = acc[i];
+  if (sp != 0) {
+    int E = ((emax_bits[b * heads + h] >> 23) & 0xff) - 127;
+    if (E < -80) E = -80;
+    sum += (float)ldexp((double)sp, E - 44);
+  }
+  out[i] = sum;
+}
+
+static inline int64_t tiled_bwd_det_pad(int B, int heads) { return ((int64_t)B * heads * 4 + 255) / 256 * 256; }
+
+// bytes of the deterministic form's workspace for these levels (0: the LDS-window backward does not take them)
+int64_t tiled_bwd_det_workspace(const int32_t* level_hw, int B, int S, int heads, int L) {
+  if (L < 1 || L > kMaxLv) return 0;
+  TiledPlan p = plan_tiled(level_hw, L, 4);
+  if (!p.ok) return 0;
+  const int64_t n_logical = (int64_t)B * heads * p.g.tiles_x * p.g.tiles_y;
+  return (int64_t)B * S * heads * 32 * 8 + tiled_bwd_det_pad(B, heads) + n_logical * p.g.lv_tab_off4 * 16;
+}
+
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
                      void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
-                     int margin, void* stream, const char* who, bool* handled) {
+                     int margin, void* stream, const char* who, bool* handled, void* det_ws) {
   *handled = false;
   if (P != 4 || L < 1 || L > kMaxLv || margin < 0 || (int64_t)Q != S) return WM2F_OK;
   TiledPlan p = plan_tiled(level_hw, L, margin);
@@ -336,10 +463,36 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
   if (n_logical > (1 << 30)) return WM2F_OK;
   const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
   hipStream_t st = (hipStream_t)stream;
+  long long* acc64 = nullptr;
+  int* emax_bits = nullptr;
+  float* staging = nullptr;
+  const int64_t n_elem = (int64_t)B * S * heads * 32;
+  int reach = 0;
+  if (det_ws) {  // [int64 spill image of grad_value][B * heads exponent words, padded][one window slab per tile]
+    if (heads * 32 > 1024 || p.g.order != 1) return WM2F_OK;
+    acc64 = (long long*)det_ws;
+    emax_bits = (int*)((char*)det_ws + n_elem * 8);
+    staging = (float*)((char*)det_ws + n_elem * 8 + tiled_bwd_det_pad(B, heads));
+    hipError_t em = hipMemsetAsync(det_ws, 0, (size_t)n_elem * 8 + (size_t)B * heads * 4, st);
+    if (em != hipSuccess) {
+      set_error("%s: clearing the workspace failed: %s", who, hipGetErrorString(em));
+      return WM2F_ELAUNCH;
+    }
+    const int rows = 64;
+    hipLaunchKernelGGL(absmax_image_head_kernel, dim3(ceil_div(Q, rows), B), dim3(heads * 32), 0, st, (const float*)grad_out, emax_bits,
+                       Q, heads, 32, rows);
+    for (int l = 0; l < L; ++l) {  // how many tiles away a window can still cover a pixel of level l
+      const int region_x = p.g.F * p.g.w[l] / p.g.w[p.g.fine], region_y = p.g.F * p.g.h[l] / p.g.h[p.g.fine];
+      const int r = p.g.M / (region_x < 1 ? 1 : region_x) + 2, r2 = p.g.M / (region_y < 1 ? 1 : region_y) + 2;
+      reach = reach > r ? reach : r;
+      reach = reach > r2 ? reach : r2;
+    }
+    if ((2 * reach + 1) * (2 * reach + 1) > 64 || heads * 32 < 64) return WM2F_OK;  // the gather tests its candidates one per lane
+  }
 #define WM2F_TB(NLv)                                                                                              \
   case NLv: {                                                                                                     \
     auto ka = msdeform_tiled_bwd_lw_kernel<NLv, 4>;                                                               \
-    auto kb = msdeform_tiled_bwd_value_kernel<NLv, 4>;                                                            \
+    auto kb = det_ws ? msdeform_tiled_bwd_value_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_kernel<NLv, 4, false>; \
     if (p.lds_bytes > 64 * 1024) {                                                                                \
       hipError_t e1 = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
       hipError_t e2 = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
@@ -352,8 +505,11 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
                        (const float*)loc, (const float*)attn_w, (const float*)grad_out, (float*)grad_loc,         \
                        (float*)grad_w, p.g, S, Q, heads, (int)n_logical, per_xcd);                                \
     hipLaunchKernelGGL(kb, dim3(per_xcd* kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)loc,         \
-                       (const float*)attn_w, (const float*)grad_out, (float*)grad_value, p.g, S, Q, heads,        \
-                       (int)n_logical, per_xcd);                                                                  \
+                       (const float*)attn_w, (const float*)grad_out, (float*)grad_value, staging, acc64, emax_bits,  \
+                       p.g, S, Q, heads, (int)n_logical, per_xcd);                                                \
+    if (det_ws)                                                                                                   \
+      hipLaunchKernelGGL(units_gather_kernel<NLv>, dim3(S, B), dim3(heads * 32), 0, st, (const float*)staging,    \
+                         (const long long*)acc64, (const int*)emax_bits, (float*)grad_value, p.g, S, heads, reach); \
   } break;
   switch (L) {
     WM2F_TB(1) WM2F_TB(2) WM2F_TB(3) WM2F_TB(4)

@@ -106,18 +106,47 @@ class _MSDeformAttn(torch.autograd.Function):
     @_amp_bwd
     def backward(ctx, grad_out):
         value, loc, attn_w = ctx.saved_tensors
-        grad_out = _req(grad_out, "grad_out")
-        B, S, H, D = value.shape
-        _, Q, _, L, P, _ = loc.shape
-        g_value = torch.zeros_like(value)
-        g_loc = torch.empty_like(loc)
-        g_w = torch.empty_like(attn_w)
-        lv = host_i32([x for hw in ctx.level_hw for x in hw])
-        with torch.cuda.device(value.device):
-            check(_timed("msdeform_bwd", value, lambda: load().wm2f_msdeform_bwd(
-                _p(value), _p(loc), _p(attn_w), _p(grad_out), _p(g_value), _p(g_loc), _p(g_w), lv, B, S, Q, H, D, L, P,
-                WM2F_F32, _stream(value))), "wm2f_msdeform_bwd")
+        g_value, g_loc, g_w = ms_deform_attn_bwd(value, ctx.level_hw, loc, attn_w, grad_out)
         return g_value, g_loc, g_w, None
+
+
+# K1 backward flavour: None = follow torch.are_deterministic_algorithms_enabled(); True / False force it.
+K1_BWD_DETERMINISTIC: bool | None = None
+
+
+def ms_deform_attn_bwd(value, level_hw, loc, attn_w, grad_out, deterministic: bool | None = None):
+    """K1 backward (the autograd of HF:798-837): (grad_value, grad_loc, grad_attn_w).  `deterministic`: the fixed-point
+    form of the grad_value scatter (wm2f_msdeform_bwd_det, run-to-run identical); default: module flag
+    K1_BWD_DETERMINISTIC, else torch's deterministic-algorithms switch.  Shapes the fixed-point form does not cover
+    raise under that switch (as torch's own ops without a deterministic form do) unless it is in warn-only mode."""
+    value, loc, attn_w = _req(value, "value"), _req(loc, "loc"), _req(attn_w, "attn_w")
+    grad_out = _req(grad_out, "grad_out")
+    B, S, H, D = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    if deterministic is None:
+        deterministic = K1_BWD_DETERMINISTIC
+    if deterministic is None:
+        deterministic = torch.are_deterministic_algorithms_enabled()
+    g_loc = torch.empty_like(loc)
+    g_w = torch.empty_like(attn_w)
+    lv = host_i32([x for hw in level_hw for x in hw])
+    with torch.cuda.device(value.device):
+        if deterministic:
+            g_value = torch.empty_like(value)
+            ws = torch.empty(max(16, int(load().wm2f_msdeform_bwd_det_workspace(lv, B, S, H, D, L))), device=value.device, dtype=torch.uint8)
+            rc = _timed("msdeform_bwd_det", value, lambda: load().wm2f_msdeform_bwd_det(
+                _p(value), _p(loc), _p(attn_w), _p(grad_out), _p(g_value), _p(g_loc), _p(g_w), _p(ws), lv, B, S, Q, H, D, L, P,
+                WM2F_F32, _stream(value)))
+            if rc != _lib.WM2F_EUNSUPPORTED:
+                check(rc, "wm2f_msdeform_bwd_det")
+                return g_value, g_loc, g_w
+            if not torch.is_deterministic_algorithms_warn_only_enabled():
+                raise RuntimeError("ms_deform_attn backward: no deterministic form for this shape (" + (load().wm2f_last_error() or b"?").decode() + ")")
+        g_value = torch.zeros_like(value)
+        check(_timed("msdeform_bwd", value, lambda: load().wm2f_msdeform_bwd(
+            _p(value), _p(loc), _p(attn_w), _p(grad_out), _p(g_value), _p(g_loc), _p(g_w), lv, B, S, Q, H, D, L, P,
+            WM2F_F32, _stream(value))), "wm2f_msdeform_bwd")
+    return g_value, g_loc, g_w
 
 
 def ms_deform_attn(value: torch.Tensor, level_hw: Sequence[Sequence[int]], loc: torch.Tensor,
