@@ -22,10 +22,12 @@
 // tools/probes/lds_atomic_rate.hip; scaling and its overflow bound are at the accumulation site):
 // kernel B 2.31 ms, kernel A 0.51 ms.
 #include "msdeform_tiled.h"
+#include <stdlib.h>
 
 namespace wm2f {
 
 constexpr int kBwdThreads = 512;
+constexpr int kQuadBwdThreads = 1024;  // the quad-form value kernel
 
 __device__ const float4 g_zero_page_bwd[1] = {{0.f, 0.f, 0.f, 0.f}};  // LDS-DMA source for out-of-image pixels
 
@@ -360,6 +362,185 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
   }
 }
 
+typedef __attribute__((address_space(3))) int lds_int_t;
+
+// ---------------------------------------------------------------------------------- kernel B, quad form
+// Same windows, fixed-point sums, flush / slab and out-of-window rule as the kernel above, but the work is laid out as in
+// the forward's quad kernels: a wave pass = 16 queries x 4 lanes, each lane owning the 8 channels {4k + j}.  Coordinates,
+// bilinear weights and window tests are then computed once per (query, point) by every lane of the quad in parallel
+// for 16 queries, instead of by 12 lanes of a wave whose other 52 wait and which then walks the 12 points serially with
+// six v_readlane each: the wave-per-query kernel issued 19.2 k vector + 10 k scalar instructions per wave (PMC: vector
+// pipe 51 % busy, the rest waits) -- 400 vector instructions per (query, head) for its 24 LDS atomics; this form needs
+// ~100.  LDS banks: at a fixed k all lanes touch dword 4k + j of their pixel row, i.e. the same 4 banks per row parity;
+// the row is therefore stored XOR-swizzled, channel c of window pixel r at dword c ^ 4 ((r >> 1) & 7), which spreads 16
+// neighbouring pixels over all 64 banks and costs nothing (v_xad_u32 forms (4k ^ 4s) + base in one instruction); the
+// flush and the slab store undo it.
+// NT threads (16 waves: 4 per SIMD, so that one wave's vector work runs under another's LDS atomics), and a pass's 12
+// points split over NSPLIT waves (21 passes per tile do not divide over 16 waves; 42 half-passes nearly do).
+template <int NL, int P, bool DET, int NT = kQuadBwdThreads, int NSPLIT = 2>
+__global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
+    const float* __restrict__ loc, const float* __restrict__ attn_w, const float* __restrict__ grad_out,
+    float* __restrict__ grad_value, float* __restrict__ staging, long long* __restrict__ acc64, const int* __restrict__ emax_bits,
+    TileGeom g, int S, int Q, int heads, int n_logical, int per_xcd) {
+  constexpr int D = 32, kWaves = NT / kWave, NP = NL * P;
+  extern __shared__ __attribute__((aligned(16))) float4 win[];
+  const int id = xcd_contiguous_id(blockIdx.x, per_xcd);
+  if (id >= n_logical) return;
+  int* lv_tab = reinterpret_cast<int*>(win + g.lv_tab_off4);
+  const TileCtx<NL> c = tile_setup<NL>(g, id, heads, lv_tab);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = lane >> 2, j = lane & 3;
+  const int row_stride = heads * D;
+  float* gvb = grad_value + ((int64_t)c.b * S * heads + c.h) * D;
+
+  for (int i = tid; i < g.lv_tab_off4; i += NT) win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // per-channel scale of the fixed-point sums: as in the kernel above (2^22 / max |grad_out| of this tile, head, channel)
+  __shared__ float ch_max[NT / kWave][32];
+  __shared__ float ch_scale[32], ch_inv[32];
+  {
+    const int ch = lane & 31;
+    float m = 0.f;
+    for (int qi = wave * 2 + (lane >> 5); qi < c.nq; qi += 2 * kWaves) {
+      const int q = tile_query<NL>(lv_tab, qi, Q);
+      m = fmaxf(m, fabsf(grad_out[(((int64_t)c.b * Q + q) * heads + c.h) * D + ch]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (lane < 32) ch_max[wave][lane] = m;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float gmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) gmax = fmaxf(gmax, ch_max[w][tid]);
+    ch_scale[tid] = gmax > 0.f ? 4194304.f / gmax : 0.f;  // 2^22 / max
+    ch_inv[tid] = gmax > 0.f ? gmax * (1.f / 4194304.f) : 0.f;
+  }
+  __syncthreads();
+  float sc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sc[k] = ch_scale[4 * k + j];
+  float det_unit_inv = 0.f;
+  long long* acc_b = nullptr;
+  if (DET) {
+    int E = ((emax_bits[c.b * heads + c.h] >> 23) & 0xff) - 127;
+    if (E < -80) E = -80;
+    det_unit_inv = __int_as_float((44 - E + 127) << 23);
+    acc_b = acc64 + ((int64_t)c.b * S * heads + c.h) * D;
+  }
+  int* wini = reinterpret_cast<int*>(win);
+  const unsigned lds_base = (unsigned)(size_t)(lds_int_t*)wini;  // 32-bit LDS address of the window
+
+  const int n_unit = ((c.nq + 15) >> 4) * NSPLIT;
+  for (int unit = wave; unit < n_unit; unit += kWaves) {
+    const int pass = unit / NSPLIT, part_pts = unit - pass * NSPLIT;
+    const int qi = pass * 16 + slot;
+    const bool valid = qi < c.nq;
+    const int q = tile_query<NL>(lv_tab, valid ? qi : c.nq - 1, Q);
+    const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
+    float raw[8], gs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      raw[k] = valid ? grad_out[pair * D + 4 * k + j] : 0.f;
+      gs[k] = raw[k] * sc[k];
+    }
+    const float* lp = loc + pair * (NP * 2);
+    const float* ap = attn_w + pair * NP;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l], wh = g.win_h[l];
+      const int base = g.lds_off4[l] * 4 + j;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        if (NSPLIT > 1 && (l * P + p) % NSPLIT != part_pts) continue;  // wave-uniform
+        const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
+        const float aw = valid ? ap[l * P + p] : 0.f;
+        float x, y;
+        pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
+        if (!(x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl) || aw == 0.f) continue;  // per lane (quad-uniform)
+        const float x0f = floorf(x), y0f = floorf(y);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float fx1 = x - x0f, fy1 = y - y0f;
+        const float a1 = aw * fy1, a0 = aw - a1;
+        const float w01 = a0 * fx1, w00 = a0 - w01, w11 = a1 * fx1, w10 = a1 - w11;
+        const bool xl = x0 >= 0, xr = x0 + 1 < Wl, yt = y0 >= 0, yb = y0 + 1 < Hl;
+        const int xrw = x0 - c.wx0[l], yrw = y0 - c.wy0[l];
+        const bool inwin = (unsigned)xrw < (unsigned)(ww - 1) && (unsigned)yrw < (unsigned)(wh - 1);
+        const float wc[4] = {w00, w01, w10, w11};
+        const bool ok[4] = {yt && xl, yt && xr, yb && xl, yb && xr};
+        if (inwin) {
+          const int r0 = yrw * ww + xrw;  // window pixel of the top-left corner
+#pragma unroll
+          for (int cn = 0; cn < 4; ++cn) {
+            if (!ok[cn]) continue;
+            const int r = r0 + (cn & 1) + (cn >> 1) * ww;
+            // byte address of (pixel r, channel 4k + j): row base + ((16 k) ^ (16 s)); (x ^ c) + y is one v_xad_u32
+            const unsigned sx = (unsigned)((r >> 1) & 7) << 4;
+            const unsigned ab = lds_base + (unsigned)(base + r * 32) * 4u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              // round half up in ONE instruction (v_cvt_rpi_i32_f32 = floor(x + 0.5); |x| < 2^22): the v_rndne + v_cvt pair
+              // of __float2int_rn and the two-instruction address were 4 of the 5 vector instructions per LDS atomic
+              int v;
+              asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(v) : "v"(wc[cn] * gs[k]));
+              __hip_atomic_fetch_add(reinterpret_cast<lds_int_t*>((size_t)((sx ^ (16u * k)) + ab)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        } else {  // rare: straight to memory
+          const int tok0 = g.start[l] + y0 * Wl + x0;
+#pragma unroll
+          for (int cn = 0; cn < 4; ++cn) {
+            if (!ok[cn]) continue;
+            const int64_t o = (int64_t)(tok0 + (cn & 1) + (cn >> 1) * Wl) * row_stride + j;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(acc_b + o + 4 * k),
+                                 (unsigned long long)__float2ll_rn(wc[cn] * raw[k] * det_unit_inv));
+              else atomicAdd(gvb + o + 4 * k, wc[cn] * raw[k]);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (DET) {  // the whole window, converted and un-swizzled, into this tile's slab
+    float4* slab = reinterpret_cast<float4*>(staging) + (int64_t)id * g.lv_tab_off4;
+    const int4* wi4 = reinterpret_cast<const int4*>(win);
+    for (int i = tid; i < g.lv_tab_off4; i += NT) {
+      int l = 0;
+#pragma unroll
+      for (int k = 1; k < NL; ++k) l += (i >= g.lds_off4[k]) ? 1 : 0;
+      int o4 = g.lds_off4[0];
+#pragma unroll
+      for (int k = 1; k < NL; ++k)
+        if (l == k) o4 = g.lds_off4[k];
+      const int r = (i - o4) >> 3, c4 = (i - o4) & 7;  // window pixel, channel group 4 c4 .. 4 c4 + 3
+      const int4 v = wi4[o4 + r * 8 + (c4 ^ ((r >> 1) & 7))];
+      const float4 si = *reinterpret_cast<const float4*>(ch_inv + 4 * c4);
+      slab[i] = make_float4((float)v.x * si.x, (float)v.y * si.y, (float)v.z * si.z, (float)v.w * si.w);
+    }
+    return;
+  }
+  // flush: one lane per channel, 32 lanes per pixel -> every atomic wave-instruction is two whole 128-B rows
+  const int pslot = tid >> 5, ch = lane & 31;
+  const float fx_inv = ch_inv[ch];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l];
+    const int npix = ww * g.win_h[l];
+    const float inv_ww = 1.f / (float)ww;
+    const int* wli = wini + g.lds_off4[l] * 4;
+    float* glev = gvb + (int64_t)g.start[l] * row_stride;
+    for (int idx = pslot; idx < npix; idx += NT / 32) {
+      const int wy = (int)(((float)idx + 0.5f) * inv_ww), wx = idx - wy * ww;
+      const int x = c.wx0[l] + wx, y = c.wy0[l] + wy;
+      if (x < 0 || x >= Wl || y < 0 || y >= Hl) continue;
+      const int vi = wli[idx * 32 + (ch ^ (((idx >> 1) & 7) << 2))];
+      if (vi != 0) atomicAdd(glev + (int64_t)(y * Wl + x) * row_stride + ch, (float)vi * fx_inv);
+    }
+  }
+}
+
 // max |grad_out| per (image, head) as float bits (non-negative floats order like their bit patterns): blockDim = heads * D
 // threads, one (head, channel) each, striding over the queries of one image chunk.
 __global__ void absmax_image_head_kernel(const float* __restrict__ go, int* __restrict__ emax_bits, int Q, int heads, int D, int rows_per_block) {
@@ -463,6 +644,12 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
   if (n_logical > (1 << 30)) return WM2F_OK;
   const int per_xcd = (int)ceil_div64(n_logical, kNumXcd);
   hipStream_t st = (hipStream_t)stream;
+#ifdef WM2F_PROFILING
+  const char* e_old = getenv("WM2F_K1_BWD_OLD");  // profiling build: the wave-per-query value kernel, for A/B
+  const bool old_form = e_old && *e_old == '1';
+#else
+  const bool old_form = false;
+#endif
   long long* acc64 = nullptr;
   int* emax_bits = nullptr;
   float* staging = nullptr;
@@ -492,7 +679,8 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
 #define WM2F_TB(NLv)                                                                                              \
   case NLv: {                                                                                                     \
     auto ka = msdeform_tiled_bwd_lw_kernel<NLv, 4>;                                                               \
-    auto kb = det_ws ? msdeform_tiled_bwd_value_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_kernel<NLv, 4, false>; \
+    auto kb = old_form ? (det_ws ? msdeform_tiled_bwd_value_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_kernel<NLv, 4, false>) \
+                       : (det_ws ? msdeform_tiled_bwd_value_quad_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_quad_kernel<NLv, 4, false>); \
     if (p.lds_bytes > 64 * 1024) {                                                                                \
       hipError_t e1 = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
       hipError_t e2 = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
@@ -504,7 +692,7 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
     hipLaunchKernelGGL(ka, dim3(per_xcd* kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)value,       \
                        (const float*)loc, (const float*)attn_w, (const float*)grad_out, (float*)grad_loc,         \
                        (float*)grad_w, p.g, S, Q, heads, (int)n_logical, per_xcd);                                \
-    hipLaunchKernelGGL(kb, dim3(per_xcd* kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)loc,         \
+    hipLaunchKernelGGL(kb, dim3(per_xcd* kNumXcd), dim3(old_form ? kBwdThreads : kQuadBwdThreads), p.lds_bytes, st, (const float*)loc, \
                        (const float*)attn_w, (const float*)grad_out, (float*)grad_value, staging, acc64, emax_bits,  \
                        p.g, S, Q, heads, (int)n_logical, per_xcd);                                                \
     if (det_ws)                                                                                                   \
