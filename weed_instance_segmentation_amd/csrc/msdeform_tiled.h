@@ -62,7 +62,7 @@ struct TiledPlan {
   bool ok;
 };
 
-// Host: choose the tile side F (16, 8, 4) so that every level's window fits 160 KiB of LDS.
+// Host: choose the tile side F (16, 8, 4) so that every level's window fits the CU's 160 KiB of LDS beside the kernels' static arrays.
 inline TiledPlan plan_tiled(const int32_t* level_hw, int L, int margin) {
   TiledPlan p{};
   p.ok = false;
@@ -92,7 +92,7 @@ inline TiledPlan plan_tiled(const int32_t* level_hw, int L, int margin) {
     }
     g.lv_tab_off4 = off4;
     off4 += 2 * kMaxLv;  // 8-int-per-level table behind the windows
-    if ((size_t)off4 * 16 <= 160 * 1024) {
+    if ((size_t)off4 * 16 <= 156 * 1024) {  // 160 KiB minus the kernels' static arrays (the backward's channel maxima: 2.3 KiB)
       g.F = F;
       g.tiles_x = (Wf + F - 1) / F;
       g.tiles_y = (Hf + F - 1) / F;
