@@ -634,9 +634,6 @@ struct StreamGeom {
   // no faster than raster (165 vs 169 us), so raster stays the default.
   int strip_w, full_strips, rem_w;
   float inv_per_strip, inv_strip_w, inv_rem_w;
-  int all_full;  // exact pyramid whose level sides are multiples of the tile (4, 8, 16): every tile has the full query counts
-  int sched;   // loader schedule: 0 = coarse(k + 1) requested under the mid gather of tile k, 1 = behind Bf(k)
-  int lanes;   // operand layout of the fused form: 0 = [offsets | logits] per token, 1 = lane-major (see fetch)
 };
 
 // exact floor(a / d) for 0 <= a < 2^22 with inv ~ 1/d (one correction step either way)
@@ -697,8 +694,9 @@ struct TileWalk {
   int b, h, tile, tx, ty;  // tx, ty: kept incrementally in raster order (no division on the per-tile path)
 };
 // `split` = workgroups per (image, head, tile): the walk's innermost index is head * split + half
+template <bool STRIPS>
 __device__ __forceinline__ void walk_xy(TileWalk& w, const StreamGeom& sg) {  // (tx, ty) of w.tile by division: start-up and strip order
-  if (sg.strip_w <= 0) {
+  if (!STRIPS || sg.strip_w <= 0) {
     w.ty = div_small(w.tile, sg.q.tiles_x, sg.inv_tiles_x);
     w.tx = w.tile - w.ty * sg.q.tiles_x;
     return;
@@ -715,6 +713,7 @@ __device__ __forceinline__ void walk_xy(TileWalk& w, const StreamGeom& sg) {  //
   w.ty = div_small(r, sg.strip_w, sg.inv_strip_w);
   w.tx = s * sg.strip_w + (r - w.ty * sg.strip_w);
 }
+template <bool STRIPS>
 __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int heads) {
   TileWalk w;
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
@@ -722,12 +721,13 @@ __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int 
   w.h = id - bt * heads;
   w.b = div_small(bt, n_tiles, sg.inv_ntiles);
   w.tile = bt - w.b * n_tiles;
-  walk_xy(w, sg);
+  walk_xy<STRIPS>(w, sg);
   return w;
 }
 // Next tile of this workgroup: `step_h` heads and `step_t` tiles further.  In raster order the tile coordinates advance with
 // a few scalar adds and compares per step (per-wave stamps: the division chains, the kernel-argument reloads they dragged in
 // and the waits behind them had made this block 3 - 6 k cycles of a 21 k-cycle tile).
+template <bool STRIPS>
 __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int heads) {
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
   int adv = sg.step_t;
@@ -741,8 +741,8 @@ __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int
     w.tile -= n_tiles;
     ++w.b;
   }
-  if (sg.strip_w > 0) {
-    walk_xy(w, sg);
+  if (STRIPS && sg.strip_w > 0) {
+    walk_xy<STRIPS>(w, sg);
     return;
   }
   for (int i = 0; i < adv; ++i) {
@@ -913,11 +913,17 @@ __device__ __forceinline__ void wave_done(int* p, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool FUSED, int MODE, int SYNC = 0, int CH = 8, bool EXACT = true>
+// OPT: compile-time form of what were run-time switches in the kernel argument (bit 0: lane-major operand rows, bit 1: the
+// round-1 loader schedule, bit 2: strip tile order).  As run-time fields they put both operand paths and both schedules
+// into the one production kernel: +29 % instructions, 60 more scalar spills, 69 kernel-argument reloads inside the tile
+// loop, and 152 -> 166 us on the model's operands (tools/probes/k1_two_libs.py, bisected over the round's commits).
+template <bool FUSED, int MODE, int SYNC = 0, int CH = 8, bool EXACT = true, int OPT = 0>
 __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_stream_fwd_kernel(
     const float* __restrict__ value, const float* __restrict__ a_in, const float* __restrict__ b_in, float* __restrict__ out,
     StreamGeom sg, int S, int Q, int heads) {
   constexpr int D = 32, NL = 3, P = 4;
+  constexpr bool kLanes = FUSED && (OPT & 1) != 0, kSched1 = (OPT & 2) == 0, kStrips = (OPT & 4) != 0;
+  constexpr bool kAllFull = EXACT && (OPT & 8) != 0;  // level sides are multiples of the tile: every tile has the full query counts
   constexpr int kLoaderWave0 = SCfg<CH>::GW, kGW = SCfg<CH>::GW, kPB = SCfg<CH>::PB, kSplit = SCfg<CH>::SPLIT;
   static_assert(SYNC == 0 || CH == 8, "the flag-synchronised form exists for the full-head kernel only");
   __shared__ __attribute__((aligned(16))) float4 win0[SWin<0, CH>::chunks * 64];
@@ -957,7 +963,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     //   under the mid gather:               F(k) part B, coarse(k + 1)       (17 + 13)
     //   under the fine gather:              [pause: the gather waves fetch their next operands]  mid(k + 1)  (21)
     constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
-    TileWalk walk = walk_init(first, sg, heads * kSplit);
+    TileWalk walk = walk_init<kStrips>(first, sg, heads * kSplit);
     LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
     loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
     __builtin_amdgcn_sched_barrier(0);
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         wait_vm<0>();
         publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
         if (k + 1 < n_my) {
-          walk_step(walk, sg, heads * kSplit);
+          walk_step<kStrips>(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           poll_ge(&ctrl[kCtrlDone + 0], kGW * (k + 1));
           loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       wg_barrier();    // Bm(k): gather waves are done with coarse(k)
       WM2F_SSTAMP(13, kLoaderWave0);
       loader_issue<2, kFA, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
-      if (sg.sched == 1) {
+      if (kSched1) {
         // Per-wave stamps (profiles/r02_k1_stream_stamps_*.json): with coarse(k + 1) requested here the loaders were the
         // last to reach Bf(k) in every workgroup, 1.5k cycles behind the gather waves.  The coarse window is not needed
         // before Bc(k + 1), a whole fine gather away: request it behind Bf together with mid(k + 1).
@@ -1005,7 +1011,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         wg_barrier();  // Bf(k): gather waves are done with mid(k)
         WM2F_SSTAMP(15, kLoaderWave0);
         if (more) {
-          walk_step(walk, sg, heads * kSplit);
+          walk_step<kStrips>(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           __builtin_amdgcn_sched_barrier(0);
           loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
@@ -1015,7 +1021,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         continue;
       }
       if (more) {
-        walk_step(walk, sg, heads * kSplit);
+        walk_step<kStrips>(walk, sg, heads * kSplit);
         lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
         __builtin_amdgcn_sched_barrier(0);
         loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         // kernel's scalar registers are its scarcest resource: every per-tile scalar spilled is a v_readlane or, worse, a
         // kernel-argument reload with its wait on the tile's critical path)
         const int Wl = g.W0 << l, Hl = g.H0 << l, fq = kQF >> (2 - l);
-        if (sg.all_full) {  // level sides are multiples of the tile: every tile holds fq x fq queries of level l
+        if (kAllFull) {  // level sides are multiples of the tile: every tile holds fq x fq queries of level l
           nqx[l] = nqy[l] = fq;
         } else {
           int nx = Wl - t.tx * fq, ny = Hl - t.ty * fq;
@@ -1156,7 +1162,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       o.qrow[t2] = q;
       const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
       const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
-      if (FUSED && sg.lanes) {
+      if (kLanes) {
         // lane-major rows (wm2f_msdeform_fused_lanes_fwd): the 9 numbers of lane j of head h are consecutive --
         // [x y] of its point on levels 0, 1, 2, then its three logits -- so a pass is 3 loads whose quad footprint is one
         // 144-byte run, instead of 6 loads scattered over the token's 1152-byte row (16 quads x 6 loads x 8 waves queued
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     return o;
   };
 
-  TileWalk walk = walk_init(first, sg, heads * kSplit);
+  TileWalk walk = walk_init<kStrips>(first, sg, heads * kSplit);
   Ops nxt = fetch(walk_tile(walk, sg, kSplit));
   for (int k = 0; k < n_my; ++k) {
     Ops cur = nxt;
@@ -1263,7 +1269,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     window_ready(2);  // Bf(k)
     WM2F_SSTAMP(6, 0);
     if (CH == 8 && k + 1 < n_my) {  // lands under the fine gather
-      walk_step(walk, sg, heads * kSplit);
+      walk_step<kStrips>(walk, sg, heads * kSplit);
       nxt = fetch(walk_tile(walk, sg, kSplit));
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1275,7 +1281,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       // half-head form: 128 registers per wave leave no room to hold the next tile's 27 operand registers through the
       // fine gather; they are requested here and land under the stores, the loop turn and the other workgroup's work
       __builtin_amdgcn_sched_barrier(0);
-      walk_step(walk, sg, heads * kSplit);
+      walk_step<kStrips>(walk, sg, heads * kSplit);
       nxt = fetch(walk_tile(walk, sg, kSplit));
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1290,7 +1296,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       if (wave_slow && cur.valid[t]) {
         unsigned todo = (unsigned)bcast<0>((int)slow[t]) | ((unsigned)bcast<1>((int)slow[t]) << 3) |
                         ((unsigned)bcast<2>((int)slow[t]) << 6) | ((unsigned)bcast<3>((int)slow[t]) << 9);
-        const bool lm = FUSED && sg.lanes;  // lane-major rows: point k2 of level l sits at [k2 * 9 + 2 * l], its logit at [k2 * 9 + 6 + l]
+        constexpr bool lm = kLanes;  // lane-major rows: point k2 of level l sits at [k2 * 9 + 2 * l], its logit at [k2 * 9 + 6 + l]
         const float* ap = lm ? a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * 36
                              : a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
         const float* bp = lm ? ap : b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
@@ -1487,23 +1493,24 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_per_strip = sg.strip_w ? 1.f / (float)(sg.strip_w * g.tiles_y) : 0.f;
   sg.inv_strip_w = sg.strip_w ? 1.f / (float)sg.strip_w : 0.f;
   sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
-  sg.all_full = (exact && g.W[2] % kQF == 0 && g.H[2] % kQF == 0) ? 1 : 0;
-  sg.sched = (mode == 300) ? 0 : 1;  // mode 300: the round-1 loader schedule (A/B measurement)
-  sg.lanes = lanes;
-  auto kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true>;
+  const bool all_full = exact && g.W[2] % kQF == 0 && g.H[2] % kQF == 0;  // e.g. every input whose sides are multiples of 128
+  const bool ln = FUSED && lanes != 0;
+  auto kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 0>;
+  if (all_full) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 8>;
   int threads = SCfg<8>::THREADS;
-  if (!exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false>;
+  if (!exact) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 0>;
   if (half) {
-    kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 4, true>;
+    kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 4, true, 0>;
     threads = SCfg<4>::THREADS;
   }
 #ifdef WM2F_PROFILING
-  if (mode == 4 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true>;
-  if (mode == 7 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true>;
-  if (mode == 74 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 4, true>;
+  if (mode == 4 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true, 0>;
+  if (mode == 7 && exact) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 1> : msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 0>;
+  if (mode == 74 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 4, true, 0>;
 #endif
-  if (mode == 100 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8, true>;  // flags instead of barriers
-  // (modes 200 / 300: the same kernel in strip tile order / with the round-1 loader schedule -- set above)
+  if (mode == 100 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8, true, 0>;  // flags instead of barriers
+  if (mode == 200 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 4>;  // 2-wide vertical strips (A/B measurement)
+  if (mode == 300 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 2>;  // the round-1 loader schedule (A/B measurement)
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(threads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();
