@@ -101,9 +101,12 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
  *                                 lanes[.., h*36 + j*9 + 6 + l]       = logits[.., h, l*4 + j]
  * A lane then fetches its 36 contiguous bytes per query (3 loads, quad footprint 144 B) instead of 6 loads scattered over
  * the 1152-byte row.  Streaming kernel only (D = 32, P = 4, L = 3 with sides 1:2:4 coarse first, Q == S); any other shape
- * returns WM2F_EUNSUPPORTED (use the [offsets | logits] form). */
+ * returns WM2F_EUNSUPPORTED (use the [offsets | logits] form).  * head_major = 0: lanes is (B, Q, heads, 36); 1: (heads, B, Q, 36) -- a head's rows of consecutive tokens contiguous, which
+ * the kernel reads in 1.1 instead of 1.9 cache lines per (token, head) (wm2f_token_linear_fwd with out_group = 36 writes
+ * that layout): 143 against 157 us launched back to back with the rows in cache, no difference behind the GEMM that
+ * wrote them. */
 int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* out, const int32_t* level_hw, int B, int S,
-                                  int Q, int heads, int D, int L, int P, int dtype, void* stream);
+                                  int Q, int heads, int D, int L, int P, int dtype, int head_major, void* stream);
 
 /* Same two operations with the kernel variant exposed (A/B measurement of kernels whose OUTPUTS ARE ALL VALID):
  *   fused   0: a = loc, b = attn_w, ref unused      1: a = offsets, b = logits, ref as above
@@ -261,10 +264,13 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
  *                        nn.Linear stores it).  Epilogue, in this order:  relu != 0: max(., 0);  ln_gamma / ln_beta != NULL:
  *                        LayerNorm over the N features of (value + residual[M, N]) (residual may be NULL) -- HF:1076-1078,
  *                        :1086-1088;  out_plus_pos != NULL: additionally out + pos[row % pos_rows] (the next layer's
- *                        `hidden + pos`, HF:972).  x / out below 2 GiB each. */
+ *                        `hidden + pos`, HF:972).  x / out below 2 GiB each.
+ *                        out_group = G > 0 (G % 4 == 0, N % G == 0, no LayerNorm): out is written (N / G, M, G), feature-group
+ *                        major, instead of (M, N): with G = 36 the merged projection writes K1's operand rows head-major
+ *                        (wm2f_msdeform_fused_lanes_fwd, head_major = 1). */
 int wm2f_token_linear_fwd(const void* x, const void* w, const void* bias, const void* residual, const void* ln_gamma,
                           const void* ln_beta, const void* pos, void* out, void* out_plus_pos, int64_t M, int K, int N, int relu,
-                          int64_t pos_rows, float eps, void* stream);
+                          int64_t pos_rows, float eps, int out_group, void* stream);
 /* wm2f_tokens_to_nchw: out (B, C, HW) = tokens (B, S, C) rows [start, start + HW) transposed per image -- the
  *                      `hidden[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` of HF:1384-1391. */
 int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int start, int HW, void* stream);

@@ -200,6 +200,9 @@ def test_k1_fused_lanes(ops, shapes, B, spread):
     packed = torch.cat([off.reshape(B, S, -1), logits.reshape(B, S, -1)], -1)
     out2 = ops.ms_deform_attn_fused_packed(dev(value), shapes, dev(packed), dev(ref_pts), H, L, P)
     assert torch.equal(out, out2)
+    # the same rows stored head-major, (heads, B, S, 36): same loads per lane from other addresses, so identical bits
+    out3 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.permute(2, 0, 1, 3, 4).reshape(H, B, S, 36).contiguous()), H, head_major=True)
+    assert torch.equal(out, out3)
     assert not ops.k1_lanes_applies([(5, 7), (10, 14), (20, 27)], 5 * 7 + 10 * 14 + 20 * 27, D, P, B, H)
     with pytest.raises(Exception):  # a shape outside the streaming kernel is refused, not re-routed
         ops.ms_deform_attn_fused_lanes(dev(value[:, :20 * 5]), [(2, 2), (4, 4), (8, 10)], dev(lanes.reshape(B, S, H * 36)[:, :100]), H)
@@ -755,6 +758,13 @@ def test_token_linear_fused_epilogues(ops, M, K, N, relu, ln, res, pos):
         bi = torch.randint(-5, 6, (N,), generator=g).float()
         exp = torch.nn.functional.linear(xi, wi, bi)
         assert torch.equal(ops.token_linear(dev(xi), dev(wi), dev(bi), relu=relu).cpu(), exp.relu() if relu else exp)
+        # feature-group-major output (N / G, M, G): the same numbers at other addresses (G = 36 for N = 288: K1's head-major
+        # operand rows; G = 64 / 4 for other splits), ragged last token tile included
+        want = exp.relu() if relu else exp
+        for G in ((36, 4) if N == 288 else (64, 4)):
+            got = ops.token_linear(dev(xi), dev(wi), dev(bi), relu=relu, out_group=G)
+            assert got.shape == (N // G, M, G)
+            assert torch.equal(got.cpu(), want.view(M, N // G, G).permute(1, 0, 2))
 
 
 @pytest.mark.parametrize("shapes,B", [([(25, 42), (50, 84), (100, 167)], 1), ([(7, 11), (13, 21), (25, 42)], 2),

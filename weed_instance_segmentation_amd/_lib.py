@@ -31,7 +31,7 @@ SIGNATURES = {
     "wm2f_msdeform_bwd_det": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "wm2f_msdeform_fused_lanes_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_msdeform_fused_lanes_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_levels_fwd": (c_int, [POINTER(c_void_p), _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_levels_bwd": (c_int, [_P, _P, _P, POINTER(c_void_p), _I, _I, _I, _I, _I, _P]),
@@ -62,7 +62,7 @@ SIGNATURES = {
                                          _I, _I, _I, c_float, c_float, c_float, _P]),
     "wm2f_bias_act": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_add_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _I, c_int64, c_float, _P]),
-    "wm2f_token_linear_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _I, _I, _I, c_int64, c_float, _P]),
+    "wm2f_token_linear_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _I, _I, _I, c_int64, c_float, _I, _P]),
     "wm2f_tokens_to_nchw": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_group_norm_tokens": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, c_float, _P]),
     "wm2f_resize_bilinear": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -425,7 +425,8 @@ extern "C" int wm2f_msdeform_fused_packed_fwd(const void* value, const void* pac
 }
 
 extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* out, const int32_t* level_hw,
-                                             int B, int S, int Q, int heads, int D, int L, int P, int dtype, void* stream) {
+                                             int B, int S, int Q, int heads, int D, int L, int P, int dtype, int head_major,
+                                             void* stream) {
   const char* who = "wm2f_msdeform_fused_lanes_fwd";
   WM2F_REQUIRE(dtype == WM2F_F32, "%s: only WM2F_F32 is built", who);
   WM2F_REQUIRE(value && lanes && out && level_hw, "%s: null pointer", who);
@@ -434,13 +435,15 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
   bool handled = false;
   if (D == 32 && L == 3 && P == 4) {
-    const int row = heads * L * P * 3;
+    // floats between consecutive tokens, and between the heads of one token: (B, Q, heads, 36), or head-major (heads, B, Q, 36)
+    const int row = head_major ? L * P * 3 : heads * L * P * 3;
+    const int head_stride = head_major ? B * Q * L * P * 3 : L * P * 3;
     int smode = 0;
 #ifdef WM2F_PROFILING
     if (const char* e = getenv("WM2F_K1_STAMP")) smode = atoi(e) ? 7 : 0;  // profiling build: the stamped kernel on the lane-major rows
 #endif
     if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, row,
-                                     row, 1))
+                                     head_stride, 1))
       return rc;
   }
   if (!handled) {

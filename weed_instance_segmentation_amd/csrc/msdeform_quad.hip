@@ -1168,7 +1168,9 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         // 144-byte run, instead of 6 loads scattered over the token's 1152-byte row (16 quads x 6 loads x 8 waves queued
         // in the texture-address unit behind the loaders' traffic: the per-wave stamps showed 3.0k cycles for the older and
         // 5.5k for the younger wave of each SIMD in this fetch)
-        const int off = (int)__umul24((unsigned)q, (unsigned)a_row) + (t.h * 36 + j * 9) * 4;
+        // b_row is the HEAD stride of the lane-major array here (144 B inside a 1152-B token row, or a whole (B, Q, 36)
+        // slab when the rows are stored head-major)
+        const int off = (int)__umul24((unsigned)q, (unsigned)a_row) + t.h * b_row + j * 36;
         const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, WM2F_OP_AUX));
         const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, WM2F_OP_AUX));
         o.lc[t2][0] = make_float2(A.x, A.y);
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         unsigned todo = (unsigned)bcast<0>((int)slow[t]) | ((unsigned)bcast<1>((int)slow[t]) << 3) |
                         ((unsigned)bcast<2>((int)slow[t]) << 6) | ((unsigned)bcast<3>((int)slow[t]) << 9);
         constexpr bool lm = kLanes;  // lane-major rows: point k2 of level l sits at [k2 * 9 + 2 * l], its logit at [k2 * 9 + 6 + l]
-        const float* ap = lm ? a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * 36
+        const float* ap = lm ? a_in + (int64_t)cur.qrow[t] * g.a_qstride + (int64_t)cur.h * g.b_qstride
                              : a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
         const float* bp = lm ? ap : b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
         auto logit_at = [&](int i) __attribute__((always_inline)) {  // i = l * P + k2
@@ -1458,8 +1460,8 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
   const int64_t n_logical = (int64_t)B * heads * split * g.tiles_x * g.tiles_y;
   const int64_t lim = 0x7fffffff;
-  if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || g.b_qstride * 4 >= (1 << 24) ||
-      (int64_t)B * Q * g.a_qstride * 4 >= lim || (int64_t)B * Q * g.b_qstride * 4 >= lim ||
+  if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || (!lanes && g.b_qstride * 4 >= (1 << 24)) || (lanes && (int64_t)heads * g.b_qstride * 4 >= lim) ||
+      (int64_t)B * Q * g.a_qstride * 4 >= lim || (!lanes && (int64_t)B * Q * g.b_qstride * 4 >= lim) ||
       (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)g.H[2] * g.W[2] >= (1 << 24) || heads * 32 * 4 >= (1 << 24) ||
       (int64_t)S * heads * 32 * 4 >= lim)
     return WM2F_OK;

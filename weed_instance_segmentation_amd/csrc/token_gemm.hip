@@ -59,6 +59,7 @@ struct TgArgs {
   float *out, *out_pos;
   int64_t M;
   int K, N, relu;
+  int out_group;  // 0: out is (M, N) row-major; G > 0 (G % 4 == 0, N % G == 0): out is (N / G, M, G) -- feature group major
   int64_t pos_rows;
   float eps;
   int tiles_total;  // ceil(M / 16)
@@ -301,6 +302,18 @@ __global__ __launch_bounds__(kTgThreads) void token_gemm_kernel(TgArgs a) {
                                                      row_o + (unsigned)(((h0 + i) * 16 + 4 * g) * 4), 0, 0);
           }
         }
+      } else if (a.out_group > 0) {
+        // group-major output (N / G, M, G): K1's operand rows head-major, so that a head's 144 bytes of consecutive tokens
+        // are contiguous.  A lane's 4 consecutive features stay inside one group (G % 4 == 0).
+        const unsigned G = (unsigned)a.out_group;
+        const unsigned grp_bytes = (unsigned)(a.M * G * 4);
+        const unsigned tok_o = tok_ok ? (unsigned)(tk * G * 4) : kOob;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+          const unsigned f0 = (unsigned)(rt * 16 + 4 * g);
+          const unsigned grp = f0 / G;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[rt][c]), o_rs, tok_o + grp * grp_bytes + (f0 - grp * G) * 4, 0, 0);
+        }
       } else {
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
@@ -317,7 +330,7 @@ using namespace wm2f;
 
 extern "C" int wm2f_token_linear_fwd(const void* x, const void* w, const void* bias, const void* residual, const void* ln_gamma,
                                      const void* ln_beta, const void* pos, void* out, void* out_plus_pos, int64_t M, int K, int N,
-                                     int relu, int64_t pos_rows, float eps, void* stream) {
+                                     int relu, int64_t pos_rows, float eps, int out_group, void* stream) {
   const char* who = "wm2f_token_linear_fwd";
   WM2F_REQUIRE(x && w && bias && out, "%s: null pointer", who);
   WM2F_REQUIRE(M > 0 && K > 0 && N > 0, "%s: non-positive size", who);
@@ -328,6 +341,8 @@ extern "C" int wm2f_token_linear_fwd(const void* x, const void* w, const void* b
   WM2F_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "%s: LayerNorm needs both gamma and beta", who);
   WM2F_REQUIRE(!residual || ln_gamma, "%s: the residual belongs to the LayerNorm epilogue", who);
   WM2F_REQUIRE(!out_plus_pos || (pos && ln_gamma && pos_rows > 0), "%s: out_plus_pos needs pos, pos_rows and the LayerNorm epilogue", who);
+  WM2F_REQUIRE(out_group == 0 || (out_group > 0 && out_group % 4 == 0 && N % out_group == 0 && !ln_gamma),
+               "%s: out_group = %d must divide N, be a multiple of 4 and exclude the LayerNorm epilogue", who, out_group);
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -352,6 +367,7 @@ extern "C" int wm2f_token_linear_fwd(const void* x, const void* w, const void* b
   a.K = K;
   a.N = N;
   a.relu = relu;
+  a.out_group = out_group;
   a.pos_rows = pos_rows;
   a.eps = eps;
   a.tiles_total = (int)ceil_div64(M, 16);

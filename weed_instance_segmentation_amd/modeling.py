@@ -67,6 +67,11 @@ _POS_CACHE: dict = {}
 # default: measured at config 2 the hand-written kernel is at parity with hipBLASLt on these shapes, not ahead
 # (DESIGN.md 4.9); WM2F_TOKEN_GEMM=1 turns it on for A/B runs.
 TOKEN_GEMM = os.environ.get("WM2F_TOKEN_GEMM", "0") == "1"
+# The merged offsets | logits projection of MSDeformAttn (inference) on that kernel with HEAD-major output rows,
+# (heads, B, S, 36).  Off by default: K1 alone, launched back to back, reads them 9 % faster (143 against 157 us: 1.1 instead
+# of 1.9 cache lines per (token, head), all served from L2 / Infinity Cache), but IN THE MODEL the rows come from HBM behind
+# the GEMM that wrote them and the launch takes the same 162 us either way.  WM2F_HEAD_MAJOR_ROWS=1 for A/B.
+HEAD_MAJOR_ROWS = os.environ.get("WM2F_HEAD_MAJOR_ROWS", "0") == "1"
 
 
 def sine_position_embedding(H: int, W: int, num_pos_feats: int, device, dtype=torch.float32, temperature=10000):
@@ -151,8 +156,14 @@ class MSDeformAttn(nn.Module):
         elif ops.k1_lanes_applies(level_hw, S, C // H, P, B, H) and hp.dtype == torch.float32:
             # inference, the encoder's own shape: one merged projection with its rows in the kernel's lane order
             w, b = self._offsets_logits_weight(lanes=True)
-            rows = ops.token_linear(hp, w, b) if tg and ops.token_linear_applies(hp, w) else F.linear(hp, w, b)
-            out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H)
+            if HEAD_MAJOR_ROWS and ops.token_linear_applies(hp, w):
+                # opt-in: the merged projection on the hand-written token GEMM, whose epilogue can write the rows HEAD-major --
+                # (heads, B, S, 36) -- see HEAD_MAJOR_ROWS above
+                rows = ops.token_linear(hp, w, b, out_group=36)
+                out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H, head_major=True)
+            else:
+                rows = ops.token_linear(hp, w, b) if tg and ops.token_linear_applies(hp, w) else F.linear(hp, w, b)
+                out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H)
         else:  # inference: one merged projection; softmax + location arithmetic fused into the kernel
             w, b = self._offsets_logits_weight()
             ol = F.linear(hp, w, b)  # (B, S, 288): [offsets (H*L*P*2) | logits (H*L*P)] per token

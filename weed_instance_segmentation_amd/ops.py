@@ -213,22 +213,24 @@ def k1_lanes_applies(level_hw, n_tokens: int, head_dim: int, n_points: int, batc
     return batch * n_tokens < (1 << 24) and batch * n_tokens * row < 0x7fffffff and batch * n_tokens * heads * 128 < 0x7fffffff
 
 
-def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int):
+def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int, head_major: bool = False):
     """Inference K1 fed by ONE merged projection whose rows are in lane-major order (include/wm2f.h,
-    wm2f_msdeform_fused_lanes_fwd): lanes (B,Q,heads*36).  Streaming kernel only -- check `k1_lanes_applies` first; a
-    shape it does not take RAISES (no silent re-route: the caller owns the row order of its projection)."""
+    wm2f_msdeform_fused_lanes_fwd): lanes (B,Q,heads*36), or head-major (heads,B,Q,36) -- what token_linear(out_group=36)
+    writes and the kernel reads in fewer cache lines.  Streaming kernel only -- check `k1_lanes_applies` first; a shape it
+    does not take RAISES (no silent re-route: the caller owns the row order of its projection)."""
     if torch.is_grad_enabled() and (value.requires_grad or lanes.requires_grad):
         raise RuntimeError("ms_deform_attn_fused_lanes has no backward; use ms_deform_attn when training")
     value, lanes = _req(_f32(value), "value"), _req(_f32(lanes), "lanes")
     B, S, H, D = value.shape
-    Q = lanes.shape[1]
-    if H != heads or lanes.shape != (B, Q, heads * 36):
-        raise ValueError(f"ms_deform_attn_fused_lanes: value {tuple(value.shape)} lanes {tuple(lanes.shape)}")
+    Q = lanes.shape[2] if head_major else lanes.shape[1]
+    if H != heads or tuple(lanes.shape) != ((heads, B, Q, 36) if head_major else (B, Q, heads * 36)):
+        raise ValueError(f"ms_deform_attn_fused_lanes: value {tuple(value.shape)} lanes {tuple(lanes.shape)} head_major={head_major}")
     out = torch.empty(B, Q, H * D, device=value.device, dtype=value.dtype)
     lv = host_i32([x for hw in level_hw for x in hw])
     with torch.cuda.device(value.device):
         check(_timed("msdeform_fused_fwd", value, lambda: load().wm2f_msdeform_fused_lanes_fwd(
-            _p(value), _p(lanes), _p(out), lv, B, S, Q, H, D, 3, 4, WM2F_F32, _stream(value))), "wm2f_msdeform_fused_lanes_fwd")
+            _p(value), _p(lanes), _p(out), lv, B, S, Q, H, D, 3, 4, WM2F_F32, 1 if head_major else 0, _stream(value))),
+            "wm2f_msdeform_fused_lanes_fwd")
     return out
 
 
@@ -620,16 +622,21 @@ def token_linear_applies(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def token_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool = False, residual: torch.Tensor | None = None,
-                 ln: tuple | None = None, pos: torch.Tensor | None = None):
+                 ln: tuple | None = None, pos: torch.Tensor | None = None, out_group: int = 0):
     """Linear over tokens with its epilogue fused (inference, no autograd): x (..., K) @ weight (N, K)^T + bias, then
     optional ReLU, optional LayerNorm(value + residual) with ln = (gamma, beta, eps), and with `pos` (rows_per_image, N)
-    additionally out + pos broadcast over the batch.  Returns out, or (out, out + pos)."""
+    additionally out + pos broadcast over the batch.  Returns out, or (out, out + pos).
+    out_group = G > 0: the result comes back feature-group major, (N // G, *x.shape[:-1], G) -- with G = 36 K1's operand rows
+    head-major (ms_deform_attn_fused_lanes(..., head_major=True))."""
     x, weight, bias = _req(x, "x"), _req(weight, "weight"), _req(bias, "bias")
     N, K = weight.shape
     if x.shape[-1] != K or bias.shape != (N,):
         raise ValueError(f"token_linear: x {tuple(x.shape)} weight {tuple(weight.shape)} bias {tuple(bias.shape)}")
     M = x.numel() // K
-    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    if out_group and (out_group % 4 or N % out_group or ln is not None):
+        raise ValueError("token_linear: out_group must divide N, be a multiple of 4 and exclude the LayerNorm epilogue")
+    out = (torch.empty(N // out_group, *x.shape[:-1], out_group, device=x.device, dtype=torch.float32) if out_group
+           else torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32))
     gamma = beta = None
     eps = 0.0
     if ln is not None:
@@ -648,7 +655,7 @@ def token_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu
     with torch.cuda.device(x.device):
         check(_timed(f"token_linear_K{K}_N{N}" + ("_ln" if ln is not None else ""), x, lambda: load().wm2f_token_linear_fwd(
             _p(x), _p(weight), _p(bias), _p(residual), _p(gamma), _p(beta), _p(pos), _p(out), _p(out_pos), M, K, N, 1 if relu else 0,
-            pos_rows, eps, _stream(x))), "wm2f_token_linear_fwd")
+            pos_rows, eps, int(out_group), _stream(x))), "wm2f_token_linear_fwd")
     return (out, out_pos) if pos is not None else out
 
 
