@@ -441,6 +441,7 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
     int smode = 0;
 #ifdef WM2F_PROFILING
     if (const char* e = getenv("WM2F_K1_STAMP")) smode = atoi(e) ? 7 : 0;  // profiling build: the stamped kernel on the lane-major rows
+    if (const char* e = getenv("WM2F_K1_MODE")) smode = atoi(e);          // profiling build: 200 strip order, 300 round-1 loader schedule
 #endif
     if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, row,
                                      head_stride, 1))

@@ -1512,6 +1512,10 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
 #endif
   if (mode == 100 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8, true, 0>;  // flags instead of barriers
   if (mode == 200 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 4>;  // 2-wide vertical strips (A/B measurement)
+#ifdef WM2F_PROFILING
+  if (mode == 200 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 5>;  // strips on the lane-major rows (in-model A/B)
+  if (mode == 300 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 3>;  // round-1 schedule on the lane-major rows
+#endif
   if (mode == 300 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 2>;  // the round-1 loader schedule (A/B measurement)
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(threads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
