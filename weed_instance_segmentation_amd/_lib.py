@@ -11,6 +11,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwm2f.so")
 PROF_LIB_PATH = os.path.join(HERE, "libwm2f_prof.so")  # profiling build (include/wm2f_prof.h): tools/ only
+if os.environ.get("WM2F_PROF_LIB"):  # tools only: another profiling build (compile-time A/B variants)
+    PROF_LIB_PATH = os.environ["WM2F_PROF_LIB"]
 
 WM2F_F32 = 0
 WM2F_BF16 = 1
