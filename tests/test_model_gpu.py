@@ -98,6 +98,41 @@ def test_train_step_backward_runs(tiny):
     assert len(grads) > 100 and all(torch.isfinite(gr).all() for gr in grads)
 
 
+def test_matched_row_mask_loss_equals_dense_route(tiny):
+    """The mask losses read the matched queries' logits from ONE recomputed einsum (loss.matched_row_logits) instead of the
+    dense per-level predictions: same loss dictionary and the same parameter gradients as the dense route (criterion.
+    matched_row_masks = False) on the same weights, labels and recorded points -- fp32, and under bf16 autocast."""
+    from weed_instance_segmentation_amd import Mask2FormerForUniversalSegmentation
+    from weed_instance_segmentation_amd.loss import ReplayPointProvider
+    g, cfg, _, sd = tiny
+    B = g["pixel_values"].shape[0]
+    n_layers = cfg.decoder_layers - 1
+    draws = [T(g[f"draw_{i}"]) for i in range(int(g["n_draws"]))][n_layers:]
+    mlg, clg = _labels(g, B)
+    x = T(g["pixel_values"]).cuda()
+    for amp in (False, True):
+        res = {}
+        for route in (True, False):
+            m = Mask2FormerForUniversalSegmentation(cfg)
+            m.load_state_dict(sd, strict=True)
+            m = m.cuda().eval()
+            m.criterion.matched_row_masks = route
+            prov = ReplayPointProvider(draws, cfg.decoder_layers, B, "cuda")
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                out = m(pixel_values=x, mask_labels=mlg, class_labels=clg, point_provider=prov)
+            out.loss.backward()
+            res[route] = ({k: v.detach().float().cpu() for k, v in out.loss_dict.items()},
+                          {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+        (la, ga), (lb, gb) = res[True], res[False]
+        assert la.keys() == lb.keys() and ga.keys() == gb.keys()
+        for k in la:
+            torch.testing.assert_close(la[k], lb[k], rtol=(2e-2 if amp else 1e-5), atol=(2e-2 if amp else 1e-6))
+        top = max(float(v.abs().max()) for v in gb.values())
+        for n in ga:  # parameters whose gradient is mathematically zero (a bias in front of a normalisation) hold rounding noise only
+            scale = max(float(gb[n].abs().max()), 1e-4 * top)
+            assert float((ga[n] - gb[n]).abs().max()) <= (6e-2 if amp else 2e-4) * scale, n
+
+
 def test_parameter_gradients_match_oracle(tiny):
     """d loss / d theta through every backward kernel (K1 atomics, K2 flash backward, K3 GEMMs, point
     sampler) against the oracle's CPU autograd on the same weights, labels and recorded points."""

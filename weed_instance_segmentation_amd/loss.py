@@ -15,6 +15,8 @@ the default provider draws on the device.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Sequence
 
 import numpy as np
@@ -82,6 +84,9 @@ class Mask2FormerLoss(nn.Module):
         self.oversample_ratio = config.oversample_ratio
         self.importance_sample_ratio = config.importance_sample_ratio
         self.batched_levels = True  # loss_masks_all_levels; False = one pass per level (kept for A/B and tests)
+        # mask losses on the matched queries' rows recomputed by one einsum (matched_row_logits) instead of the dense
+        # predictions; WM2F_MATCHED_ROW_MASKS=0 (or this attribute) restores the dense route for A/B and tests
+        self.matched_row_masks = os.environ.get("WM2F_MATCHED_ROW_MASKS", "1") != "0"
         self.cost_class, self.cost_mask, self.cost_dice = config.class_weight, config.mask_weight, config.dice_weight
         self.world_size_fn = None  # set by parallel.DataParallelEngine: all-reduces num_masks (HF:781-794)
 
@@ -174,10 +179,46 @@ class Mask2FormerLoss(nn.Module):
         loss_dice = (1 - (num + 1) / (den + 1)).sum() / num_masks  # HF:278-305
         return loss_mask, loss_dice
 
-    def loss_masks_all_levels(self, all_masks, tgt, offsets, indices, num_masks, order, provider):
+    def matched_row_logits(self, rows, indices, order):
+        """The mask logits of the MATCHED queries only, for every level of `order`, from ONE einsum: rows =
+        (inter, mask_embedder, mask_features) -- the decoder's normalised states per level (B, Q, d), the mask-embedding
+        MLP and the pixel features (HF:2040-2046).  The dependency takes these rows out of the dense (B, Q, H, W)
+        predictions (HF:602-609), whose backward is then a dense einsum backward per level over 100 query rows of which
+        at most `targets` are non-zero, plus nine accumulations of the 0.5 GB pixel-feature gradient.  Recomputing the
+        matched rows -- (B, levels x T_max, C) embeddings against the same pixel features, same kernel, same per-row sums --
+        makes that backward ONE einsum backward over levels x T_max rows; the dense predictions keep feeding the matcher
+        and the caller and receive no gradient from this loss.  Returns (maps (B * NL * T_max, h, w) fp32, index (NL, M))."""
+        inter, embedder, pix = rows
+        B = pix.shape[0]
+        NL = len(order)
+        dev = pix.device
+        counts = [int(s.numel()) for s, _ in indices[order[0]]]
+        t_max = max(max(counts), 1)
+        b_idx = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
+        t_idx = torch.cat([torch.arange(c) for c in counts]).to(dev)
+        q_idx = torch.stack([torch.cat([s for s, _ in indices[lvl]]) for lvl in order]).to(dev)  # (NL, M)
+        h_m = torch.stack([inter[lvl][b_idx, q_idx[n]] for n, lvl in enumerate(order)])            # (NL, M, d)
+        emb_m = embedder(h_m)                                                                     # (NL, M, C)
+        C = emb_m.shape[-1]
+        e_all = emb_m.new_zeros(B, NL * t_max, C)
+        slot = (torch.arange(NL, device=dev)[:, None] * t_max + t_idx[None, :])                     # (NL, M)
+        e_all = e_all.index_put((b_idx[None, :].expand(NL, -1), slot), emb_m)
+        if pix.dtype == torch.bfloat16 and pix.shape[1] % 32 == 0 and pix.shape[1] <= 512:
+            pix_c = pix.contiguous()
+            pix_t = ops.nchw_to_pixel_major_bf16(pix_c)
+            per = max(1, 112 // t_max) * t_max  # whole levels per call, at most 112 rows: the bf16 backward kernel's limit
+            parts = [ops.mask_einsum_bf16(e_all[:, r0:r0 + per].contiguous(), pix_c, pix_t) for r0 in range(0, NL * t_max, per)]
+            logits = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+        else:
+            logits = ops.mask_einsum(e_all.float(), pix.float())
+        index = (b_idx[None, :] * (NL * t_max) + slot).to(torch.int32)
+        return logits.reshape(B * NL * t_max, logits.shape[2], logits.shape[3]), index
+
+    def loss_masks_all_levels(self, all_masks, tgt, offsets, indices, num_masks, order, provider, rows=None):
         """`loss_masks` for every level of `order` in one pass: the level tensors are sampled where
         they are (pointer table), the top-k, the target sampling and the BCE / dice reductions run once over
-        (levels x matched masks) rows.  Returns two (len(order),) tensors: loss_mask, loss_dice per level."""
+        (levels x matched masks) rows.  Returns two (len(order),) tensors: loss_mask, loss_dice per level.
+        rows: see `matched_row_logits` -- the predictions are then sampled from the matched-row maps."""
         dev = all_masks[0].device
         B, Q, h, w = all_masks[0].shape
         NL, P = len(order), self.num_points
@@ -189,12 +230,16 @@ class Mask2FormerLoss(nn.Module):
             return z, z
         pred_idx = pred_idx.to(device=dev, dtype=torch.int32)
         tgt_idx = tgt_idx.to(device=dev, dtype=torch.int32)
-        maps = [all_masks[lvl].reshape(B * Q, h, w).float() for lvl in order]
+        if rows is not None:
+            compact, cidx = self.matched_row_logits(rows, indices, order)
+            maps, pred_idx, lv_shape = [compact], cidx.view(1, NL * M), (1, NL * M)
+        else:
+            maps, lv_shape = [all_masks[lvl].reshape(B * Q, h, w).float() for lvl in order], (NL, M)
         n_over = int(P * self.oversample_ratio)
         n_unc = int(self.importance_sample_ratio * P)
         with torch.no_grad():
             pc = torch.stack([provider.oversample_points(lvl, M, n_over) for lvl in order])  # (NL, M, n_over, 2)
-            unc = ops.point_sample_levels([m.detach() for m in maps], pc, pred_idx, neg_abs=True)
+            unc = ops.point_sample_levels([m.detach() for m in maps], pc.view(*lv_shape, n_over, 2), pred_idx, neg_abs=True)
             idx = torch.topk(unc.view(NL * M, n_over), k=n_unc, dim=1)[1]
             pts = torch.gather(pc.view(NL * M, n_over, 2), 1, idx[..., None].expand(-1, -1, 2))
             if P - n_unc > 0:
@@ -202,12 +247,14 @@ class Mask2FormerLoss(nn.Module):
                 pts = torch.cat([pts, rnd], 1)
             pts = pts.contiguous()
             point_labels = ops.point_sample(tgt, pts, tgt_idx.view(-1))
-        point_logits = ops.point_sample_levels(maps, pts.view(NL, M, P, 2), pred_idx)
+        point_logits = ops.point_sample_levels(maps, pts.view(*lv_shape, P, 2), pred_idx)
         bce, dice = ops.mask_loss_rows(point_logits.view(NL * M, P), point_labels)
         return bce.view(NL, M).sum(1) / num_masks, dice.view(NL, M).sum(1) / num_masks
 
-    def forward(self, all_masks, all_classes, mask_labels, class_labels, point_provider=None):
+    def forward(self, all_masks, all_classes, mask_labels, class_labels, point_provider=None, matched_rows=None):
         """all_masks / all_classes: per-level lists in decoder order, LAST = final prediction.
+        matched_rows = (inter, mask_embedder, mask_features), lists in the same level order: the mask losses then read the
+        matched queries' logits from one recomputed einsum (`matched_row_logits`) instead of the dense predictions.
         Returns (weighted loss dict with the dependency's key names, indices of the final level)."""
         NL, B = len(all_masks), all_masks[0].shape[0]
         dev = all_masks[0].device
@@ -232,7 +279,8 @@ class Mask2FormerLoss(nn.Module):
         same_m = len({sum(int(s.numel()) for s, _ in indices[lvl]) for lvl in order}) == 1
         batched = self.batched_levels and same_m and NL <= 16
         if batched:
-            lm_all, ld_all = self.loss_masks_all_levels(all_masks, tgt, offsets, indices, num_masks, order, provider)
+            rows = matched_rows if (matched_rows is not None and self.matched_row_masks and all_masks[0].is_cuda) else None
+            lm_all, ld_all = self.loss_masks_all_levels(all_masks, tgt, offsets, indices, num_masks, order, provider, rows=rows)
             lc_all = self.loss_labels_all_levels(all_classes, cls, offsets, indices, order)
         for n, lvl in enumerate(order):
             if batched:

@@ -652,9 +652,11 @@ class Mask2FormerForUniversalSegmentation(nn.Module):
         loss = loss_dict = indices = None
         if mask_labels is not None and class_labels is not None:
             use_aux = self.config.use_auxiliary_loss
+            embedder = self.model.transformer_module.decoder.mask_predictor.mask_embedder
             loss_dict, indices = self.criterion(all_logits if use_aux else all_logits[-1:],
                                                 all_classes if use_aux else all_classes[-1:], mask_labels, class_labels,
-                                                point_provider=point_provider)
+                                                point_provider=point_provider,
+                                                matched_rows=(inter if use_aux else inter[-1:], embedder, mask_features))
             loss = sum(loss_dict.values())
         out = Mask2FormerForUniversalSegmentationOutput(
             loss=loss, class_queries_logits=all_classes[-1], masks_queries_logits=all_logits[-1],
