@@ -283,6 +283,22 @@ def main():
             flop = 4 * B * H * Q * N * D
             r.update(flop=flop, TFLOPs=flop / r["med_us"] / 1e6, kv_bytes=2 * B * N * E * 4)
             res[f"k2_masked_xattn_N{N}"] = r
+    if "k2b" in only:  # K2 forward + backward through autograd (the backward alone = difference to the k2 line); --prof: WM2F_K2_BWD_FULL=0
+        E = H * D
+        for hw in (shapes[-1:] if a.fine_only else shapes):
+            N = hw[0] * hw[1]
+            q = (torch.randn(B, Q, E, device=dev) * 0.3).requires_grad_()
+            k = torch.randn(B, N, E, device=dev).requires_grad_()
+            v = torch.randn(B, N, E, device=dev).requires_grad_()
+            mask = (torch.rand(B, Q, N, device=dev) < 0.5).to(torch.uint8)
+            ro = torch.ones(B, Q, device=dev, dtype=torch.int32)
+            go = torch.randn(B, Q, E, device=dev)
+
+            def fb():
+                o = ops.masked_xattn(q, k, v, mask, ro, H)
+                o.backward(go)
+                q.grad = k.grad = v.grad = None
+            res[f"k2_fwd_plus_bwd_N{N}"] = timeit(fb, a.iters)
     if "k4" in only:
         NL, Tn, Pn = 10, 16, 12544
         ml = torch.randn(NL, B, Q, 256, 256, device=dev)

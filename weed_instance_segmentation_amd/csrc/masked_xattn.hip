@@ -971,6 +971,206 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bwd_kernel(
   }
 }
 
+// Full-tile form of the backward (N % 16 == 0, one query chunk covers Q, D = 32): what the general kernel above fetched
+// from global memory inside its (key tile, query tile) loop -- the q / grad_out rows as A operands in both orientations
+// (~24 loads), lse, delta and row_open of the lane's four rows (12 loads), four mask bytes -- ~40 memory instructions beside
+// 40 MFMAs, none of them prefetched (the loop was kept rolled) -- comes from LDS here: q, grad_out, (lse, delta) of the
+// workgroup's <= 112 queries are staged ONCE; K, V (both orientations) and the mask bytes of key tile t + 4 are requested
+// through buffer descriptors before the arithmetic of tile t, into a second register set; the query-tile loop is unrolled.
+// Rows beyond Q carry lse = +inf (p = 0 without a branch); rows that do not use the mask read it through an out-of-range
+// offset (zeros).  dQ partials of the four waves meet in LDS that re-uses the staging area.
+template <int NQT>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bwd_full_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ go, float* __restrict__ dq_ws,
+    float* __restrict__ dk, float* __restrict__ dv, int Q, int N, int heads, int n_splits, int tiles_per_split) {
+  constexpr int D = 32, DK = 8, DT = 2, QL = NQT * 16, RS = D + 4, TS = 20;
+  constexpr int kStage = 2 * QL * RS + 3 * QL, kPart = kXWaves * QL * D;
+  __shared__ __attribute__((aligned(16))) float lds[(kStage > kPart ? kStage : kPart)];
+  __shared__ __attribute__((aligned(16))) float tr[kXWaves][16][TS];
+  float* qs = lds;                  // [QL][RS]
+  float* gs = lds + QL * RS;        // [QL][RS]
+  float* ld2 = lds + 2 * QL * RS;   // [QL][2] = (lse, delta)
+  uint32_t* moff = reinterpret_cast<uint32_t*>(lds + 2 * QL * RS + 2 * QL);  // [QL] byte offset of the row in the mask, or out of range
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int E = heads * D;
+  const float* qb = q + (int64_t)b * Q * E + h * D;
+  const float* gob = go + (int64_t)b * Q * E + h * D;
+  for (int i = tid; i < QL * (D / 4); i += kXWaves * kWave) {
+    const int r = i / (D / 4), c = i - r * (D / 4);
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+    if (r < Q) {
+      x = *reinterpret_cast<const float4*>(qb + (int64_t)r * E + 4 * c);
+      y = *reinterpret_cast<const float4*>(gob + (int64_t)r * E + 4 * c);
+    }
+    *reinterpret_cast<float4*>(qs + r * RS + 4 * c) = x;
+    *reinterpret_cast<float4*>(gs + r * RS + 4 * c) = y;
+  }
+  for (int r = tid; r < QL; r += kXWaves * kWave) {
+    const bool ok = r < Q;
+    ld2[2 * r] = ok ? lse[((int64_t)b * heads + h) * Q + r] : INFINITY;  // p = exp(s - inf) = 0 for padding rows
+    ld2[2 * r + 1] = ok ? delta[((int64_t)b * heads + h) * Q + r] : 0.f;
+    // a row that does not use the mask (or a padding row) reads it out of range = 0 = open
+    const bool use = mask != nullptr && ok && (row_open == nullptr || row_open[(int64_t)b * Q + r] != 0);
+    moff[r] = use ? (uint32_t)(r * N) : 0x80000000u;
+  }
+  __syncthreads();
+
+  const int n_tiles = N / 16;
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * N * E), 0, N * E * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * N * E), 0, N * E * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(mask != nullptr ? mask + (int64_t)b * Q * N : nullptr), 0, mask != nullptr ? Q * N : 0, 0x00020000);
+  const uint32_t kv_voff = (uint32_t)((n * E + h * D + DK * g) * 4);   // lane (key0 + n, d = 8 g + t)
+  const uint32_t kr_voff = (uint32_t)((4 * g * E + h * D + n) * 4);    // lane (key0 + 4 g + t, d = 16 i + n)
+  const int row_bytes = E * 4;
+  struct Frag {
+    f32x4 kf[2], vf[2];  // B operands of S / dP
+    float kr[DT][4];     // B operand of dQ
+    uint32_t mb[4];      // mask bytes of query tile 0 (the later query tiles' bytes are requested one tile ahead inside compute)
+  };
+  auto load_tile = [&](int tile, Frag& f) __attribute__((always_inline)) {
+    if (tile > n_tiles - 1) tile = n_tiles - 1;  // the prefetch past the end re-reads a valid tile and is discarded
+    const int soff = tile * 16 * row_bytes;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f.kf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kv_voff + 16 * c, soff, 0));
+      f.vf[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, kv_voff + 16 * c, soff, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+        f.kr[i][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k_rsrc, kr_voff + 64 * i, soff + t * row_bytes, 0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f.mb[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(m_rsrc, moff[4 * g + r] + (uint32_t)n, tile * 16, 0);
+  };
+
+  f32x4 dqa[NQT][DT];
+#pragma unroll
+  for (int jq = 0; jq < NQT; ++jq)
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dqa[jq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* dvb = dv + (int64_t)b * N * E + h * D;
+  float* dkb = dk + (int64_t)b * N * E + h * D;
+
+  auto compute = [&](const Frag& f, int tile, bool live) __attribute__((always_inline)) {
+    f32x4 dvt[DT], dkt[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dvt[i] = dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t mcur[4] = {f.mb[0], f.mb[1], f.mb[2], f.mb[3]};
+#pragma unroll
+    for (int jq = 0; jq < NQT; ++jq) {
+      uint32_t mnxt[4] = {0u, 0u, 0u, 0u};
+      if (jq + 1 < NQT) {  // the next query tile's mask bytes: (query 16 (jq + 1) + 4 g + r, key key0 + n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          mnxt[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(m_rsrc, moff[16 * (jq + 1) + 4 * g + r] + (uint32_t)n, tile * 16, 0);
+      }
+      // A operands of S and dP from LDS: lane (q = 16 jq + n, d = 8 g + t)
+      const f32x4 qa0 = *reinterpret_cast<const f32x4*>(qs + (16 * jq + n) * RS + DK * g);
+      const f32x4 qa1 = *reinterpret_cast<const f32x4*>(qs + (16 * jq + n) * RS + DK * g + 4);
+      const f32x4 ga0 = *reinterpret_cast<const f32x4*>(gs + (16 * jq + n) * RS + DK * g);
+      const f32x4 ga1 = *reinterpret_cast<const f32x4*>(gs + (16 * jq + n) * RS + DK * g + 4);
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[t], f.kf[0][t], sacc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0[t], f.vf[0][t], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1[t], f.kf[1][t], sacc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1[t], f.vf[1][t], dp, 0, 0, 0);
+      }
+      f32x4 p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // rows of this lane: q = 16 jq + 4 g + r
+        const float2 ld = *reinterpret_cast<const float2*>(ld2 + 2 * (16 * jq + 4 * g + r));
+        float pv = __expf(sacc[r] - ld.x);
+        pv = (mcur[r] != 0u || !live) ? 0.f : pv;
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - ld.y);
+      }
+      // A operands of dV^T / dK^T from LDS: lane (d = 16 i + n, q = 16 jq + 4 g + t)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+          const float got = gs[(16 * jq + 4 * g + t) * RS + 16 * i + n];
+          const float qt = qs[(16 * jq + 4 * g + t) * RS + 16 * i + n];
+          dvt[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(got, p[t], dvt[i], 0, 0, 0);
+          dkt[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt, ds[t], dkt[i], 0, 0, 0);
+        }
+      }
+      // dS to the query-on-lane layout through the wave's LDS tile, then dQ += dS K
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tr[wave][4 * g + r][n] = ds[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const f32x4 dsa = *reinterpret_cast<const f32x4*>(&tr[wave][n][4 * g]);  // lane (q = n, keys 4 g .. 4 g + 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dqa[jq][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsa[t], f.kr[i][t], dqa[jq][i], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mcur[r] = mnxt[r];
+    }
+    if (live) {  // dV^T / dK^T tiles: column = key n, rows d = 16 i + 4 g + r  ->  float4 along d; this wave is the keys' only writer
+      const int64_t ko = (int64_t)(tile * 16 + n) * E;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        *reinterpret_cast<f32x4*>(dvb + ko + 16 * i + 4 * g) = dvt[i];
+        *reinterpret_cast<f32x4*>(dkb + ko + 16 * i + 4 * g) = dkt[i];
+      }
+    }
+  };
+
+  Frag fa, fb;
+  int tile = split * tiles_per_split + wave;
+  load_tile(tile, fa);
+  while (tile < t_end) {
+    load_tile(tile + kXWaves, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fa, tile, true);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(tile + 2 * kXWaves, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fb, tile + kXWaves, tile + kXWaves < t_end);
+    __builtin_amdgcn_sched_barrier(0);
+    tile += 2 * kXWaves;
+  }
+
+  // ---- merge dQ over the 4 waves through LDS (re-using the staging area): C layout of dqa is (column = d n, rows q = 4 g + r)
+  __syncthreads();
+  float* part = lds;  // [kXWaves][QL][D]
+#pragma unroll
+  for (int jq = 0; jq < NQT; ++jq)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(wave * QL + 16 * jq + 4 * g + r) * D + 16 * i + n] = dqa[jq][i][r];
+  __syncthreads();
+  for (int idx = tid; idx < QL * (D / 4); idx += kXWaves * kWave) {
+    const int ql = idx / (D / 4), c = idx - ql * (D / 4);
+    if (ql >= Q) continue;
+    float4 a = *reinterpret_cast<const float4*>(part + ql * D + 4 * c);
+#pragma unroll
+    for (int w = 1; w < kXWaves; ++w) {
+      const float4 x = *reinterpret_cast<const float4*>(part + (w * QL + ql) * D + 4 * c);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+    *reinterpret_cast<float4*>(dq_ws + ((((int64_t)b * heads + h) * Q + ql) * n_splits + split) * D + 4 * c) = a;
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void xattn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq,
                                                               int B, int heads, int Q, int n_splits) {
@@ -1027,6 +1227,12 @@ extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v
       }                                                                                                            \
     }                                                                                                              \
     dim3 grid(n_splits* q_chunks, heads, B);                                                                       \
+    if (full_bwd && Dv == 32 && q_chunks == 1)                                                                     \
+      hipLaunchKernelGGL((masked_xattn_bwd_full_kernel<NQTv>), dim3(n_splits, heads, B), dim3(kXWaves* kWave), 0, st, \
+                         (const float*)q, (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open, \
+                         (const float*)lse, (const float*)delta, (const float*)grad_out, dq_ws, (float*)grad_k,    \
+                         (float*)grad_v, Q, N, heads, n_splits, tps);                                              \
+    else                                                                                                           \
     hipLaunchKernelGGL((masked_xattn_bwd_kernel<NQTv, Dv>), grid, dim3(kXWaves* kWave), 0, st, (const float*)q,    \
                        (const float*)k, (const float*)v, (const uint8_t*)mask, (const int*)row_open,               \
                        (const float*)lse, (const float*)delta, (const float*)grad_out, dq_ws, (float*)grad_k,      \
@@ -1035,6 +1241,10 @@ extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v
                        st, (const float*)dq_ws, (float*)grad_q, B, heads, Q, n_splits);                            \
   }
   const int q_tiles = ceil_div(Q, 16);
+  // full-tile backward: whole key tiles, 32-bit byte offsets (the general kernel takes every other shape)
+  const bool full_bwd = D == 32 && (N % 16) == 0 && (int64_t)N * heads * D * 4 < (int64_t(1) << 31) && (int64_t)Q * N < (int64_t(1) << 31) &&
+                        tps >= 8 &&  // each workgroup stages its 112 query rows once: with 4 tiles per split (N = 1024) that costs more than it saves (237 against 189 us)
+                        tune_env("WM2F_K2_BWD_FULL", 1) != 0;
   if (D == 16) {
     if (q_tiles <= 4) WM2F_BD(16, 4) else WM2F_BD(16, 7)
   } else if (D == 32) {
