@@ -308,12 +308,18 @@ int wm2f_group_norm_act(const void* x, const void* gamma, const void* beta, cons
  *   int32 DEVICE: which map of its level row m samples.
  * wm2f_point_sample_levels_fwd: out (n_levels, M, P); neg_abs != 0 stores -|value| (the uncertainty, HF:688-690).
  * wm2f_point_sample_levels_bwd: atomically adds grad_out * bilinear weights into the (zero-initialised) level_grads.
+ * wm2f_point_sample_levels_bwd_unique: the same when every (level, index) pair is distinct (the matched rows of a
+ *                               one-to-one assignment): each indexed map is accumulated band by band in LDS and
+ *                               OVERWRITTEN with plain stores (no global atomics; maps that no row indexes are not
+ *                               touched -- clear those).  W <= 16384.
  * wm2f_mask_loss_rows_fwd:      logits, labels (R, P) -> bce_mean (R), dice (R), sums (R, 4) kept for the backward.
  * wm2f_mask_loss_rows_bwd:      grad (R, P) = g_bce[r] * d bce_mean[r] + g_dice[r] * d dice[r]. */
 int wm2f_point_sample_levels_fwd(const void* const* level_maps, int n_levels, const void* pts, const int32_t* index,
                                  void* out, int M, int H, int W, int P, int neg_abs, void* stream);
 int wm2f_point_sample_levels_bwd(const void* grad_out, const void* pts, const int32_t* index,
                                  void* const* level_grads, int n_levels, int M, int H, int W, int P, void* stream);
+int wm2f_point_sample_levels_bwd_unique(const void* grad_out, const void* pts, const int32_t* index,
+                                        void* const* level_grads, int n_levels, int M, int H, int W, int P, void* stream);
 int wm2f_mask_loss_rows_fwd(const void* logits, const void* labels, void* sums, void* bce_mean, void* dice,
                             int R, int P, void* stream);
 int wm2f_mask_loss_rows_bwd(const void* logits, const void* labels, const void* sums, const void* g_bce,

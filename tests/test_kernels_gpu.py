@@ -797,3 +797,38 @@ def test_k1_streaming_kernel_on_pyramids_that_are_not_1_2_4(ops, shapes, B):
         torch.testing.assert_close(out_f.cpu(), ref, rtol=1e-4, atol=2e-5 * max(1.0, shapes[2][1] / 32))
         torch.testing.assert_close(out_u, out_d, rtol=1e-4, atol=1e-5)
     assert not ops.k1_lanes_applies(shapes, S, D, P, B, H)  # the lane-major rows stay with the exact pyramids
+
+
+# ----------------------------------------------------------------------------------------- point sampling over levels
+@pytest.mark.parametrize("NL,N,M,H,W,P", [(3, 7, 5, 64, 64, 300),      # one band per map
+                                          (2, 6, 4, 150, 256, 1000),   # 64-row bands, the last one ragged, points on band seams
+                                          (1, 9, 9, 33, 50, 257),      # pixel count not a multiple of 4
+                                          (4, 3, 3, 8, 12, 40)])
+def test_point_sample_levels_forward_and_both_backwards(ops, NL, N, M, H, W, P):
+    """sample_point (HF:245-274 = grid_sample, bilinear, align_corners False, zero padding) over level maps that are not
+    stacked: forward against torch's grid_sample, and the two backward forms -- global atomics (any index) and the LDS
+    band form for distinct indices (maps overwritten, untouched maps stay zero) -- against autograd of the same."""
+    g = torch.Generator().manual_seed(41)
+    maps = [torch.randn(N, H, W, generator=g) for _ in range(NL)]
+    pts = torch.rand(NL, M, P, 2, generator=g) * 1.1 - 0.05  # some points outside [0, 1]
+    pts[:, :, :8, 1] = torch.tensor([63.5, 64.0, 64.49, 64.5, 127.5, 128.0, 0.0, H - 0.01]) / H  # band seams and borders
+    index = torch.stack([torch.randperm(N, generator=g)[:M] for _ in range(NL)]).to(torch.int32)
+    go = torch.randn(NL, M, P, generator=g)
+    refs, ref_grads = [], []
+    for l in range(NL):
+        ml = maps[l].clone().requires_grad_()
+        sel = ml[index[l].long()][:, None]                                  # (M, 1, H, W)
+        out = torch.nn.functional.grid_sample(sel, 2.0 * pts[l][:, None] - 1.0, mode="bilinear", padding_mode="zeros", align_corners=False)[:, 0, 0]
+        out.backward(go[l])
+        refs.append(out.detach())
+        ref_grads.append(ml.grad)
+    for unique in (False, True):
+        dm = [dev(m).requires_grad_() for m in maps]
+        out = ops.point_sample_levels(dm, dev(pts), dev(index), unique_index=unique)
+        torch.testing.assert_close(out.cpu(), torch.stack(refs), rtol=1e-5, atol=1e-5)
+        out.backward(dev(go))
+        for l in range(NL):
+            torch.testing.assert_close(dm[l].grad.cpu(), ref_grads[l], rtol=1e-4, atol=1e-5)
+            untouched = torch.ones(N, dtype=torch.bool)
+            untouched[index[l].long()] = False
+            assert float(dm[l].grad[dev(untouched)].abs().max() if untouched.any() else 0.0) == 0.0

@@ -78,6 +78,50 @@ __global__ __launch_bounds__(256) void point_sample_levels_bwd_kernel(const floa
   if (yb && xr) atomicAdd(g + W + 1, go * fx1 * fy1);
 }
 
+// The same scatter when every (level, index) pair is distinct (the matched rows of a one-to-one assignment): a workgroup owns
+// a BAND of one indexed map in LDS (16 K pixels = 64 KiB), walks all P points of the row, adds the corners that fall into its
+// band with LDS atomics, and writes the band back with plain coalesced stores -- the map is OVERWRITTEN (no clearing needed,
+// no global atomics: 64 M of them per step cost 3 ms at config 2).
+__global__ __launch_bounds__(256) void point_sample_levels_bwd_band_kernel(const float* __restrict__ grad_out,
+                                                                           const float* __restrict__ pts,
+                                                                           const int32_t* __restrict__ index, LevelTableMut grads,
+                                                                           int M, int H, int W, int P, int band_rows) {
+  extern __shared__ __attribute__((aligned(16))) float band[];  // [band_rows][W]
+  const int bnd = blockIdx.x, m = blockIdx.y, l = blockIdx.z, tid = threadIdx.x;
+  const int y_lo = bnd * band_rows, y_hi = min(H, y_lo + band_rows);
+  const int n_px = (y_hi - y_lo) * W;
+  for (int i = tid; i < n_px; i += 256) band[i] = 0.f;
+  __syncthreads();
+  const int64_t row = (int64_t)l * M + m;
+  const float2* pp = reinterpret_cast<const float2*>(pts) + row * P;
+  const float* gp = grad_out + row * P;
+  for (int p = tid; p < P; p += 256) {
+    const float2 pt = pp[p];
+    const float go = gp[p];
+    const float x = ((2.f * pt.x - 1.f + 1.f) * (float)W - 1.f) * 0.5f;
+    const float y = ((2.f * pt.y - 1.f + 1.f) * (float)H - 1.f) * 0.5f;
+    if (!(x > -1.f && x < (float)W && y > -1.f && y < (float)H)) continue;
+    const float x0f = floorf(x), y0f = floorf(y);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    if (y0 + 1 < y_lo || y0 >= y_hi) continue;
+    const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+    const bool xl = x0 >= 0, xr = x0 + 1 < W;
+    const bool yt = y0 >= y_lo, yb = y0 + 1 < y_hi;  // inside the band implies inside the image
+    float* g = band + (y0 - y_lo) * W + x0;
+    if (yt && xl) atomicAdd(g, go * fx0 * fy0);
+    if (yt && xr) atomicAdd(g + 1, go * fx1 * fy0);
+    if (yb && xl) atomicAdd(g + W, go * fx0 * fy1);
+    if (yb && xr) atomicAdd(g + W + 1, go * fx1 * fy1);
+  }
+  __syncthreads();
+  float* dst = grads.p[l] + (int64_t)index[row] * H * W + (int64_t)y_lo * W;
+  if ((n_px & 3) == 0 && (W & 3) == 0) {
+    for (int i = tid; i < n_px / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(band)[i];
+  } else {
+    for (int i = tid; i < n_px; i += 256) dst[i] = band[i];
+  }
+}
+
 __device__ __forceinline__ float block_sum256(float v, float* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -191,6 +235,30 @@ extern "C" int wm2f_mask_loss_rows_bwd(const void* logits, const void* labels, c
   hipLaunchKernelGGL(mask_loss_rows_bwd_kernel, dim3(ceil_div(P, 256), R), dim3(256), 0, (hipStream_t)stream,
                      (const float*)logits, (const float*)labels, (const float*)sums, (const float*)g_bce,
                      (const float*)g_dice, (float*)grad, P);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+extern "C" int wm2f_point_sample_levels_bwd_unique(const void* grad_out, const void* pts, const int32_t* index,
+                                                   void* const* level_grads, int n_levels, int M, int H, int W, int P,
+                                                   void* stream) {
+  const char* who = "wm2f_point_sample_levels_bwd_unique";
+  WM2F_REQUIRE(grad_out && pts && index && level_grads, "%s: null pointer", who);
+  WM2F_REQUIRE(n_levels > 0 && n_levels <= kMaxLossLevels, "%s: 1..%d levels", who, kMaxLossLevels);
+  WM2F_REQUIRE(M > 0 && M < 65536 && H > 0 && W > 0 && P > 0, "%s: bad size", who);
+  if (W > 16384) {
+    set_error("%s: maps wider than 16384 pixels do not fit a band", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  LevelTableMut tab;
+  for (int l = 0; l < kMaxLossLevels; ++l) tab.p[l] = (float*)level_grads[l < n_levels ? l : 0];
+  for (int l = 0; l < n_levels; ++l) WM2F_REQUIRE(tab.p[l], "%s: null level pointer", who);
+  int band_rows = 16384 / W;  // 64 KiB of LDS
+  if (band_rows > H) band_rows = H;
+  const int bands = ceil_div(H, band_rows);
+  const size_t lds = (size_t)band_rows * W * 4;
+  hipLaunchKernelGGL(point_sample_levels_bwd_band_kernel, dim3(bands, M, n_levels), dim3(256), lds, (hipStream_t)stream,
+                     (const float*)grad_out, (const float*)pts, index, tab, M, H, W, P, band_rows);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }

@@ -247,7 +247,7 @@ class Mask2FormerLoss(nn.Module):
                 pts = torch.cat([pts, rnd], 1)
             pts = pts.contiguous()
             point_labels = ops.point_sample(tgt, pts, tgt_idx.view(-1))
-        point_logits = ops.point_sample_levels(maps, pts.view(*lv_shape, P, 2), pred_idx)
+        point_logits = ops.point_sample_levels(maps, pts.view(*lv_shape, P, 2), pred_idx, unique_index=True)  # a one-to-one assignment: no map twice
         bce, dice = ops.mask_loss_rows(point_logits.view(NL * M, P), point_labels)
         return bce.view(NL, M).sum(1) / num_masks, dice.view(NL, M).sum(1) / num_masks
 

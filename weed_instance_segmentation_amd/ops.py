@@ -811,7 +811,7 @@ def _ptr_table(tensors):
 class _PointSampleLevels(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
-    def forward(ctx, pts, index, neg_abs, *maps):
+    def forward(ctx, pts, index, neg_abs, unique, *maps):
         maps = [_req(m, "level map") for m in maps]
         pts, index = _req(pts, "pts"), _req(index, "index", torch.int32)
         NL, M, P = pts.shape[:3]
@@ -825,6 +825,7 @@ class _PointSampleLevels(torch.autograd.Function):
                 "wm2f_point_sample_levels_fwd")
         ctx.save_for_backward(pts, index)
         ctx.shape = (NL, N, H, W)
+        ctx.unique = bool(unique) and W <= 16384
         return out
 
     @staticmethod
@@ -834,17 +835,20 @@ class _PointSampleLevels(torch.autograd.Function):
         NL, N, H, W = ctx.shape
         grad_out = _req(grad_out, "grad_out")
         grads = [torch.zeros(N, H, W, device=pts.device, dtype=torch.float32) for _ in range(NL)]
+        fn = load().wm2f_point_sample_levels_bwd_unique if ctx.unique else load().wm2f_point_sample_levels_bwd
         with torch.cuda.device(pts.device):
-            check(_timed("point_sample_levels_bwd", pts, lambda: load().wm2f_point_sample_levels_bwd(
+            check(_timed("point_sample_levels_bwd", pts, lambda: fn(
                 _p(grad_out), _p(pts), _p(index), _ptr_table(grads), NL, pts.shape[1], H, W, pts.shape[2], _stream(pts))),
                 "wm2f_point_sample_levels_bwd")
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
-def point_sample_levels(maps, pts: torch.Tensor, index: torch.Tensor, neg_abs: bool = False) -> torch.Tensor:
+def point_sample_levels(maps, pts: torch.Tensor, index: torch.Tensor, neg_abs: bool = False, unique_index: bool = False) -> torch.Tensor:
     """sample_point (HF:245-274) on one (N,H,W) map tensor PER LEVEL without stacking them: pts (NL,M,P,2) in [0,1]
-    (x,y), index (NL,M) int32 = which map of its level row m samples -> (NL,M,P).  neg_abs: -|value| (HF:688-690)."""
-    return _PointSampleLevels.apply(pts, index, bool(neg_abs), *maps)
+    (x,y), index (NL,M) int32 = which map of its level row m samples -> (NL,M,P).  neg_abs: -|value| (HF:688-690).
+    unique_index: the caller guarantees that no map is indexed twice within a level (the matched rows of a one-to-one
+    assignment) -- the backward then accumulates each map in LDS bands and stores it, without global atomics."""
+    return _PointSampleLevels.apply(pts, index, bool(neg_abs), bool(unique_index), *maps)
 
 
 class _MaskLossRows(torch.autograd.Function):
