@@ -101,10 +101,11 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
  *                                 lanes[.., h*36 + j*9 + 6 + l]       = logits[.., h, l*4 + j]
  * A lane then fetches its 36 contiguous bytes per query (3 loads, quad footprint 144 B) instead of 6 loads scattered over
  * the 1152-byte row.  Streaming kernel only (D = 32, P = 4, L = 3 with sides 1:2:4 coarse first, Q == S); any other shape
- * returns WM2F_EUNSUPPORTED (use the [offsets | logits] form).  * head_major = 0: lanes is (B, Q, heads, 36); 1: (heads, B, Q, 36) -- a head's rows of consecutive tokens contiguous, which
+ * returns WM2F_EUNSUPPORTED (use the [offsets | logits] form).  * head_major bit 0 = 0: lanes is (B, Q, heads, 36); 1: (heads, B, Q, 36) -- a head's rows of consecutive tokens contiguous, which
  * the kernel reads in 1.1 instead of 1.9 cache lines per (token, head) (wm2f_token_linear_fwd with out_group = 36 writes
  * that layout): 143 against 157 us launched back to back with the rows in cache, no difference behind the GEMM that
- * wrote them. */
+ * wrote them.  head_major bit 1: `value` is stored (heads, B, S, 32) instead of (B, S, heads, 32) (what
+ * wm2f_token_linear_fwd with out_group = 32 writes): a head's window rows become contiguous runs. */
 int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* out, const int32_t* level_hw, int B, int S,
                                   int Q, int heads, int D, int L, int P, int dtype, int head_major, void* stream);
 

@@ -203,6 +203,9 @@ def test_k1_fused_lanes(ops, shapes, B, spread):
     # the same rows stored head-major, (heads, B, S, 36): same loads per lane from other addresses, so identical bits
     out3 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.permute(2, 0, 1, 3, 4).reshape(H, B, S, 36).contiguous()), H, head_major=True)
     assert torch.equal(out, out3)
+    # value stored head-major, (heads, B, S, 32): the loaders read the same pixels through other strides
+    out4 = ops.ms_deform_attn_fused_lanes(dev(value.permute(2, 0, 1, 3).contiguous()), shapes, dev(lanes.reshape(B, S, H * 36)), H, value_head_major=True)
+    assert torch.equal(out, out4)
     assert not ops.k1_lanes_applies([(5, 7), (10, 14), (20, 27)], 5 * 7 + 10 * 14 + 20 * 27, D, P, B, H)
     with pytest.raises(Exception):  # a shape outside the streaming kernel is refused, not re-routed
         ops.ms_deform_attn_fused_lanes(dev(value[:, :20 * 5]), [(2, 2), (4, 4), (8, 10)], dev(lanes.reshape(B, S, H * 36)[:, :100]), H)

@@ -436,15 +436,16 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
   bool handled = false;
   if (D == 32 && L == 3 && P == 4) {
     // floats between consecutive tokens, and between the heads of one token: (B, Q, heads, 36), or head-major (heads, B, Q, 36)
-    const int row = head_major ? L * P * 3 : heads * L * P * 3;
-    const int head_stride = head_major ? B * Q * L * P * 3 : L * P * 3;
+    const bool rows_hm = (head_major & 1) != 0, value_hm = (head_major & 2) != 0;
+    const int row = rows_hm ? L * P * 3 : heads * L * P * 3;
+    const int head_stride = rows_hm ? B * Q * L * P * 3 : L * P * 3;
     int smode = 0;
 #ifdef WM2F_PROFILING
     if (const char* e = getenv("WM2F_K1_STAMP")) smode = atoi(e) ? 7 : 0;  // profiling build: the stamped kernel on the lane-major rows
     if (const char* e = getenv("WM2F_K1_MODE")) smode = atoi(e);          // profiling build: 200 strip order, 300 round-1 loader schedule
 #endif
     if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, row,
-                                     head_stride, 1))
+                                     head_stride, 1 | (value_hm ? 2 : 0)))
       return rc;
   }
   if (!handled) {

@@ -634,6 +634,9 @@ struct StreamGeom {
   // no faster than raster (165 vs 169 us), so raster stays the default.
   int strip_w, full_strips, rem_w;
   float inv_per_strip, inv_strip_w, inv_rem_w;
+  // layout of `value` in floats: pixel pitch, and the head / image strides -- (B, S, heads, 32) or head-major (heads, B, S, 32)
+  int v_pix;
+  long long v_head, v_img;
 };
 
 // exact floor(a / d) for 0 <= a < 2^22 with inv ~ 1/d (one correction step either way)
@@ -844,8 +847,8 @@ struct LoaderTile {  // wave-uniform per-tile values of the loaders
 __device__ __forceinline__ LoaderTile loader_tile(const float* value, const StreamGeom& sg, const TileId& t, int S, int heads,
                                                   int pixel_bytes = 128) {
   const QuadGeom& g = sg.q;
-  const int row_stride = heads * 32, row_bytes = row_stride * 4;
-  const float* vb = value + ((int64_t)t.b * S * heads + t.h) * 32 + t.hh * 16;  // this head's slice (its second half: + 16 channels)
+  const int row_stride = sg.v_pix, row_bytes = row_stride * 4;
+  const float* vb = value + (int64_t)t.b * sg.v_img + (int64_t)t.h * sg.v_head + t.hh * 16;  // this head's slice (its second half: + 16 channels)
   LoaderTile lt;
   lt.x_border = false;
 #pragma unroll
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
   const int first = xcd * sg.per_xcd + lw;
   if (n_my <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row_stride = heads * D, row_bytes = row_stride * 4;
+  const int row_stride = sg.v_pix, row_bytes = row_stride * 4;
   __shared__ int ctrl[kCtrlWords];
   if (SYNC == 1) {
     if (tid < kCtrlWords) ctrl[tid] = 0;
@@ -1289,7 +1292,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     }
 
     // ---- slow points (rare), then the stores
-    const float* vb = value + ((int64_t)cur.b * S * heads + cur.h) * D + cur.hh * 16;
+    const float* vb = value + (int64_t)cur.b * sg.v_img + (int64_t)cur.h * sg.v_head + cur.hh * 16;
     const bool wave_slow = __builtin_amdgcn_ballot_w64((slow[0] | slow[1] | slow[2]) != 0) != 0;
 #pragma unroll
     for (int t = 0; t < kPasses; ++t) {
@@ -1460,8 +1463,8 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   g.b_qstride = b_qstride > 0 ? b_qstride : heads * L * P;
   const int64_t n_logical = (int64_t)B * heads * split * g.tiles_x * g.tiles_y;
   const int64_t lim = 0x7fffffff;
-  if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || (!lanes && g.b_qstride * 4 >= (1 << 24)) || (lanes && (int64_t)heads * g.b_qstride * 4 >= lim) ||
-      (int64_t)B * Q * g.a_qstride * 4 >= lim || (!lanes && (int64_t)B * Q * g.b_qstride * 4 >= lim) ||
+  if (n_logical >= (1 << 22) || (int64_t)B * Q >= (1 << 24) || g.a_qstride * 4 >= (1 << 24) || (!(lanes & 1) && g.b_qstride * 4 >= (1 << 24)) || ((lanes & 1) && (int64_t)heads * g.b_qstride * 4 >= lim) ||
+      (int64_t)B * Q * g.a_qstride * 4 >= lim || (!(lanes & 1) && (int64_t)B * Q * g.b_qstride * 4 >= lim) ||
       (int64_t)B * Q * heads * 32 * 4 >= lim || (int64_t)g.H[2] * g.W[2] >= (1 << 24) || heads * 32 * 4 >= (1 << 24) ||
       (int64_t)S * heads * 32 * 4 >= lim)
     return WM2F_OK;
@@ -1496,7 +1499,11 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_strip_w = sg.strip_w ? 1.f / (float)sg.strip_w : 0.f;
   sg.inv_rem_w = sg.rem_w ? 1.f / (float)sg.rem_w : 0.f;
   const bool all_full = exact && g.W[2] % kQF == 0 && g.H[2] % kQF == 0;  // e.g. every input whose sides are multiples of 128
-  const bool ln = FUSED && lanes != 0;
+  const bool v_hm = (lanes & 2) != 0;  // value stored head-major, (heads, B, S, 32)
+  sg.v_pix = v_hm ? 32 : heads * 32;
+  sg.v_head = v_hm ? (long long)B * S * 32 : 32;
+  sg.v_img = v_hm ? (long long)S * 32 : (long long)S * heads * 32;
+  const bool ln = FUSED && (lanes & 1) != 0;
   auto kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 0>;
   if (all_full) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 8>;
   int threads = SCfg<8>::THREADS;

@@ -72,6 +72,7 @@ TOKEN_GEMM = os.environ.get("WM2F_TOKEN_GEMM", "0") == "1"
 # of 1.9 cache lines per (token, head), all served from L2 / Infinity Cache), but IN THE MODEL the rows come from HBM behind
 # the GEMM that wrote them and the launch takes the same 162 us either way.  WM2F_HEAD_MAJOR_ROWS=1 for A/B.
 HEAD_MAJOR_ROWS = os.environ.get("WM2F_HEAD_MAJOR_ROWS", "0") == "1"
+HEAD_MAJOR_VALUE = os.environ.get("WM2F_HEAD_MAJOR_VALUE", "0") == "1"  # the same question for the value tensor (A/B)
 
 
 def sine_position_embedding(H: int, W: int, num_pos_feats: int, device, dtype=torch.float32, temperature=10000):
@@ -142,6 +143,14 @@ class MSDeformAttn(nn.Module):
             hp = hidden + pos[None]
         tg = (TOKEN_GEMM and not torch.is_grad_enabled() and ops.token_linear_applies(hidden, self.value_proj.weight)
               and not torch.is_autocast_enabled("cuda"))
+        v_hm = (HEAD_MAJOR_VALUE and not torch.is_grad_enabled() and hp.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
+                and ops.token_linear_applies(hidden, self.value_proj.weight) and ops.k1_lanes_applies(level_hw, S, C // H, P, B, H))
+        if v_hm:  # A/B: value written head-major, (heads, B, S, 32), by the token GEMM
+            value = ops.token_linear(hidden, self.value_proj.weight, self.value_proj.bias, out_group=C // H)
+            w, b = self._offsets_logits_weight(lanes=True)
+            out = ops.ms_deform_attn_fused_lanes(value, level_hw, F.linear(hp, w, b), H, value_head_major=True)
+            return self.output_proj(out) if fuse_ln is None else ops.token_linear(
+                out, self.output_proj.weight, self.output_proj.bias, residual=fuse_ln[0], ln=(fuse_ln[1].weight, fuse_ln[1].bias, fuse_ln[1].eps))
         if tg:  # the narrow token GEMMs on the hand-written fp32 MFMA kernel (csrc/token_gemm.hip)
             value = ops.token_linear(hidden, self.value_proj.weight, self.value_proj.bias).view(B, S, H, C // H)
         else:
