@@ -1,5 +1,5 @@
 """K1 inside the model (configs[1] forward, B 8) with the profiling build's in-model switches: WM2F_K1_MODE = 200 (tiles of an
-image walked in 2-wide vertical strips), 300 (round-1 loader schedule), unset (raster, the shipped kernel).  kbench / probe
+image walked in 2-wide vertical strips), 500 (Z-order), 300 (round-1 loader schedule), unset (raster, the shipped kernel).  kbench / probe
 launches run with the operands in cache; only in the model is the launch fed from HBM, which is where a tile order that
 re-uses window halos in L2 could matter.  Usage: python tools/k1_inmodel_modes.py"""
 import json, os, sys
@@ -12,7 +12,7 @@ import bench
 dev = torch.device("cuda:0")
 model = bench.build_model().to(dev).eval()
 x = torch.randn(8, 3, 1024, 1024, device=dev)
-for mode in ("", "200", "300", "", "200", "300"):
+for mode in ("", "500", "200", "300", "", "500", "200", "300"):
     if mode:
         os.environ["WM2F_K1_MODE"] = mode
     else:

@@ -697,9 +697,18 @@ struct TileWalk {
   int b, h, tile, tx, ty;  // tx, ty: kept incrementally in raster order (no division on the per-tile path)
 };
 // `split` = workgroups per (image, head, tile): the walk's innermost index is head * split + half
-template <bool STRIPS>
+template <int ORDER>  // 0 raster, 1 strips, 2 Z-order
 __device__ __forceinline__ void walk_xy(TileWalk& w, const StreamGeom& sg) {  // (tx, ty) of w.tile by division: start-up and strip order
-  if (!STRIPS || sg.strip_w <= 0) {
+  if (ORDER == 2) {  // Z-order (square power-of-two tile grids): de-interleave the bits of the tile index
+    unsigned x = (unsigned)w.tile & 0x5555u, y = ((unsigned)w.tile >> 1) & 0x5555u;
+    x = (x | (x >> 1)) & 0x3333u; y = (y | (y >> 1)) & 0x3333u;
+    x = (x | (x >> 2)) & 0x0f0fu; y = (y | (y >> 2)) & 0x0f0fu;
+    x = (x | (x >> 4)) & 0x00ffu; y = (y | (y >> 4)) & 0x00ffu;
+    w.tx = (int)x;
+    w.ty = (int)y;
+    return;
+  }
+  if (ORDER != 1 || sg.strip_w <= 0) {
     w.ty = div_small(w.tile, sg.q.tiles_x, sg.inv_tiles_x);
     w.tx = w.tile - w.ty * sg.q.tiles_x;
     return;
@@ -716,7 +725,7 @@ __device__ __forceinline__ void walk_xy(TileWalk& w, const StreamGeom& sg) {  //
   w.ty = div_small(r, sg.strip_w, sg.inv_strip_w);
   w.tx = s * sg.strip_w + (r - w.ty * sg.strip_w);
 }
-template <bool STRIPS>
+template <int ORDER>
 __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int heads) {
   TileWalk w;
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
@@ -724,13 +733,13 @@ __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int 
   w.h = id - bt * heads;
   w.b = div_small(bt, n_tiles, sg.inv_ntiles);
   w.tile = bt - w.b * n_tiles;
-  walk_xy<STRIPS>(w, sg);
+  walk_xy<ORDER>(w, sg);
   return w;
 }
 // Next tile of this workgroup: `step_h` heads and `step_t` tiles further.  In raster order the tile coordinates advance with
 // a few scalar adds and compares per step (per-wave stamps: the division chains, the kernel-argument reloads they dragged in
 // and the waits behind them had made this block 3 - 6 k cycles of a 21 k-cycle tile).
-template <bool STRIPS>
+template <int ORDER>
 __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int heads) {
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
   int adv = sg.step_t;
@@ -744,8 +753,8 @@ __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int
     w.tile -= n_tiles;
     ++w.b;
   }
-  if (STRIPS && sg.strip_w > 0) {
-    walk_xy<STRIPS>(w, sg);
+  if (ORDER == 2 || (ORDER == 1 && sg.strip_w > 0)) {
+    walk_xy<ORDER>(w, sg);
     return;
   }
   for (int i = 0; i < adv; ++i) {
@@ -926,6 +935,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     StreamGeom sg, int S, int Q, int heads) {
   constexpr int D = 32, NL = 3, P = 4;
   constexpr bool kLanes = FUSED && (OPT & 1) != 0, kSched1 = (OPT & 2) == 0, kStrips = (OPT & 4) != 0;
+  constexpr int kOrder = (OPT & 16) ? 2 : (kStrips ? 1 : 0);
   constexpr bool kAllFull = EXACT && (OPT & 8) != 0;  // level sides are multiples of the tile: every tile has the full query counts
   constexpr int kLoaderWave0 = SCfg<CH>::GW, kGW = SCfg<CH>::GW, kPB = SCfg<CH>::PB, kSplit = SCfg<CH>::SPLIT;
   static_assert(SYNC == 0 || CH == 8, "the flag-synchronised form exists for the full-head kernel only");
@@ -966,7 +976,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     //   under the mid gather:               F(k) part B, coarse(k + 1)       (17 + 13)
     //   under the fine gather:              [pause: the gather waves fetch their next operands]  mid(k + 1)  (21)
     constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
-    TileWalk walk = walk_init<kStrips>(first, sg, heads * kSplit);
+    TileWalk walk = walk_init<kOrder>(first, sg, heads * kSplit);
     LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
     loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
     __builtin_amdgcn_sched_barrier(0);
@@ -982,7 +992,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         wait_vm<0>();
         publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
         if (k + 1 < n_my) {
-          walk_step<kStrips>(walk, sg, heads * kSplit);
+          walk_step<kOrder>(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           poll_ge(&ctrl[kCtrlDone + 0], kGW * (k + 1));
           loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
@@ -1014,7 +1024,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         wg_barrier();  // Bf(k): gather waves are done with mid(k)
         WM2F_SSTAMP(15, kLoaderWave0);
         if (more) {
-          walk_step<kStrips>(walk, sg, heads * kSplit);
+          walk_step<kOrder>(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           __builtin_amdgcn_sched_barrier(0);
           loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         continue;
       }
       if (more) {
-        walk_step<kStrips>(walk, sg, heads * kSplit);
+        walk_step<kOrder>(walk, sg, heads * kSplit);
         lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
         __builtin_amdgcn_sched_barrier(0);
         loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
@@ -1193,7 +1203,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     return o;
   };
 
-  TileWalk walk = walk_init<kStrips>(first, sg, heads * kSplit);
+  TileWalk walk = walk_init<kOrder>(first, sg, heads * kSplit);
   Ops nxt = fetch(walk_tile(walk, sg, kSplit));
   for (int k = 0; k < n_my; ++k) {
     Ops cur = nxt;
@@ -1274,7 +1284,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     window_ready(2);  // Bf(k)
     WM2F_SSTAMP(6, 0);
     if (CH == 8 && k + 1 < n_my) {  // lands under the fine gather
-      walk_step<kStrips>(walk, sg, heads * kSplit);
+      walk_step<kOrder>(walk, sg, heads * kSplit);
       nxt = fetch(walk_tile(walk, sg, kSplit));
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1286,7 +1296,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       // half-head form: 128 registers per wave leave no room to hold the next tile's 27 operand registers through the
       // fine gather; they are requested here and land under the stores, the loop turn and the other workgroup's work
       __builtin_amdgcn_sched_barrier(0);
-      walk_step<kStrips>(walk, sg, heads * kSplit);
+      walk_step<kOrder>(walk, sg, heads * kSplit);
       nxt = fetch(walk_tile(walk, sg, kSplit));
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1493,6 +1503,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   // tile work order inside an image: plain raster; mode 200 = 2-wide vertical strips (see StreamGeom; A/B measurement:
   // 169 against 165 us -- the seams a strip order saves were not what the kernel waits for)
   sg.strip_w = (mode == 200 && g.tiles_x >= 2) ? 2 : 0;
+  const bool zorder = mode == 500 && g.tiles_x == g.tiles_y && (g.tiles_x & (g.tiles_x - 1)) == 0 && g.tiles_x <= 256;  // (A/B)
   sg.full_strips = sg.strip_w ? g.tiles_x / sg.strip_w : 0;
   sg.rem_w = sg.strip_w ? g.tiles_x - sg.full_strips * sg.strip_w : 0;
   sg.inv_per_strip = sg.strip_w ? 1.f / (float)(sg.strip_w * g.tiles_y) : 0.f;
@@ -1521,6 +1532,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   if (mode == 200 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 4>;  // 2-wide vertical strips (A/B measurement)
 #ifdef WM2F_PROFILING
   if (mode == 200 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 5>;  // strips on the lane-major rows (in-model A/B)
+  if (zorder && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 25>;  // Z-order tile walk (in-model A/B)
   if (mode == 300 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 3>;  // round-1 schedule on the lane-major rows
 #endif
   if (mode == 300 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 2>;  // the round-1 loader schedule (A/B measurement)
