@@ -12,7 +12,7 @@ import bench
 dev = torch.device("cuda:0")
 model = bench.build_model().to(dev).eval()
 x = torch.randn(8, 3, 1024, 1024, device=dev)
-for mode in ("", "500", "200", "300", "", "500", "200", "300"):
+for mode in ("", "600", "700", "500", "", "600", "700", "500"):
     if mode:
         os.environ["WM2F_K1_MODE"] = mode
     else:

@@ -1055,6 +1055,10 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
   }
 
   // -------------------------------------------------------------------- gather waves
+  // OPT bit 5 (A/B): the second-dispatched half of the gather waves (4 - 7: the loser of every issue arbitration with its SIMD's
+  // older wave, and the waves the per-wave stamps show on the critical path) at static priority 1
+  if ((OPT & 32) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if ((OPT & 64) && wave < 4) __builtin_amdgcn_s_setprio(1);  // the opposite choice
   const int j = tid & 3, quad = lane >> 2;
   const int xq = (0x73261540 >> ((quad & 7) * 4)) & 7;  // bank-aware quad -> query order, see the kernel above
   const int slot = wave * 16 + (quad & 8) + xq;
@@ -1533,6 +1537,8 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
 #ifdef WM2F_PROFILING
   if (mode == 200 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 5>;  // strips on the lane-major rows (in-model A/B)
   if (zorder && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 25>;  // Z-order tile walk (in-model A/B)
+  if (mode == 600 && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 41>;  // younger gather waves at priority 1
+  if (mode == 700 && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 73>;  // older gather waves at priority 1
   if (mode == 300 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 3>;  // round-1 schedule on the lane-major rows
 #endif
   if (mode == 300 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 2>;  // the round-1 loader schedule (A/B measurement)
