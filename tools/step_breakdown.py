@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel totals of the LAST forward step in a rocprofv3 kernel trace of bench.py (fwd mode).
-usage: step_breakdown.py <kernel_trace.csv> [top_n]"""
+"""Per-kernel totals of the LAST step in a rocprofv3 kernel trace of bench.py.
+usage: step_breakdown.py <kernel_trace.csv> [top_n] [marker]   marker: substring of a kernel launched exactly once per step
+(default: the forward's markers; for --mode train use matcher_cost_kernel)"""
 import collections
 import csv
 import sys
@@ -8,7 +9,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [r for r in rows if "resize_pyramid" in r["Kernel_Name"]]  # one per forward (the level-resolution mask route)
+marker = sys.argv[3] if len(sys.argv) > 3 else "resize_pyramid"  # one per forward (the level-resolution mask route)
+marks = [r for r in rows if marker in r["Kernel_Name"]]
 if len(marks) >= 2:
     t0, t1 = int(marks[-2]["Start_Timestamp"]), int(marks[-1]["Start_Timestamp"])
 else:  # no pyramid launch in the trace: every prediction at full resolution -- 10 mask builds per forward close a step
