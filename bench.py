@@ -17,6 +17,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline_k3   same for the mask einsum against the fp32 MFMA peak.
   cpu_baseline  the CPU oracle (oracle/m2f_oracle.py, kind "port") timed on this host on a
                 bounded sample of the same workload (N = 1, rank 0 only).
+  train_step    BASELINE.json configs[2] beside the headline line (N = 1, default flags only): a short bf16-autocast
+                full train step leg at batch 16 (Hungarian matching + losses + backward + AdamW), run AFTER the timed
+                forward region and the CPU sample -- ms per step, images/sec and the K1 / K2 / K3 launch times.
+                `value` / `metric` stay configs[1].
 """
 from __future__ import annotations
 
@@ -33,6 +37,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
+# HBM bytes per K1 launch from the PMC counters of a separate rocprofv3 run over this same command (tools/pmc_bench.sh;
+# counters cannot be collected inside the driver's own run): the newest committed measurement
+K1_TRAFFIC_PROFILE = "r02_pmc_k1_traffic.json"
 
 
 def build_model(seed=0, num_labels=3, num_queries=100):
@@ -76,6 +83,42 @@ def cpu_baseline(model, size, n_images, seed=0):
                 seconds=dt), res, x
 
 
+def train_leg(dev, batch=16, size=1024, warmup=2, steps=3, amp=True, seed=0):
+    """BASELINE.json configs[2]: full train step under bf16 autocast at `batch` images of `size`^2, synthetic labels
+    (16 rectangles per image), AdamW lr 5e-5 (train.py:174).  A fresh model; HIP-event launch times of the wm2f kernels."""
+    from weed_instance_segmentation_amd import ops
+    from weed_instance_segmentation_amd.parallel import DataParallelEngine
+    model = build_model(seed).to(dev).train()
+    g = torch.Generator(device="cpu").manual_seed(2000)
+    x = torch.randn(batch, 3, size, size, generator=g).to(dev)
+    ml, cl = synthetic_labels(batch, size, size, seed=0, device=dev)
+    engine = DataParallelEngine(model, lr=5e-5)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out = model(pixel_values=x, mask_labels=ml, class_labels=cl)
+        engine.backward_and_step(out.loss)
+        return out.loss.detach()
+
+    for _ in range(warmup):
+        loss = step()
+    timer = ops.KernelTimer()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    ks = timer.summary()
+    return {"workload": f"BASELINE.json configs[2]: synthetic {size}x{size} 3-class, ResNet-50 Mask2Former, 100 queries, "
+                        f"{'bf16 autocast' if amp else 'fp32'} full train step (Hungarian matching + mask/dice/class loss + backward + AdamW), bs={batch}",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "images_per_sec": round(batch * steps / dt, 2),
+            "loss": round(float(loss), 4), "finite": bool(torch.isfinite(loss)),
+            "kernels_us": {k: {"launches_per_step": n // steps, "avg_us": round(us, 1)} for k, (n, us) in sorted(ks.items())}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +128,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--train-leg", type=int, default=1, help="1: after the default run also time a short configs[2] train leg (0 = skip)")
     ap.add_argument("--amp", choices=["off", "bf16"], default="off",
                     help="bf16: run the step under torch.autocast(bfloat16) (BASELINE configs 3-5); the wm2f kernels keep fp32 arithmetic")
     a = ap.parse_args()
@@ -185,7 +229,7 @@ def main():
             nbytes = 4 * (2 * B * Stok * H * D + B * Stok * H * L * P * 3)
             ach = nbytes / us / 1e3
             traffic = None  # HBM bytes per launch from PMC counters of a separate rocprofv3 run (profiles/)
-            tpath = os.path.join(ROOT, "profiles", "r02_pmc_k1_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", K1_TRAFFIC_PROFILE)
             if B == 8 and S == 1024 and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
             line["roofline"] = {"kernel": k1_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -210,6 +254,9 @@ def main():
             cb["mask_logit_max_abs_err"] = float((o.masks_queries_logits.cpu() - ref).abs().max())
             cb["mask_logit_rel_err"] = cb["mask_logit_max_abs_err"] / float(ref.abs().max())
             line["cpu_baseline"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in cb.items()}
+        if world == 1 and a.train_leg and which == "BASELINE.json configs[1]":
+            torch.cuda.empty_cache()  # 288 GB of HBM: the forward model simply stays resident beside the train leg's
+            line["train_step"] = train_leg(dev)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -102,6 +102,26 @@ def test_ddp_gloo_world2_accumulation2(tmp_path):
 
 
 def test_ddp_gloo_world2_reduce_scatter_form(tmp_path):
-    """exchange="reduce_scatter": buckets padded to whole shards; under gloo (no reduce_scatter_tensor) the exchange
-    object takes its all-reduce form -- same parameters either way."""
+    """exchange="reduce_scatter": buckets padded to whole shards; reduce_scatter_tensor (in place, the rank's shard a view of
+    the bucket) -> mean on the shard -> all_gather_into_tensor, the code RCCL runs -- including a bucket whose parameter got
+    no gradient (Tiny.unused: launched from finish()) -- gives the same parameters as the all-reduce form."""
     _run(2, tmp_path, exchange="reduce_scatter")
+
+
+def test_reduce_scatter_exchange_calls_the_two_collectives(tmp_path, monkeypatch):
+    """Guard against the exchange silently taking another route: a one-rank gloo group, the collectives counted."""
+    import torch.distributed as dist
+    from weed_instance_segmentation_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = []
+        rs, ag = dist.reduce_scatter_tensor, dist.all_gather_into_tensor
+        monkeypatch.setattr(dist, "reduce_scatter_tensor", lambda *a, **k: (calls.append("rs"), rs(*a, **k))[1])
+        monkeypatch.setattr(dist, "all_gather_into_tensor", lambda *a, **k: (calls.append("ag"), ag(*a, **k))[1])
+        flat = torch.arange(6, dtype=torch.float32)
+        h = parallel._ScatterGather(flat, 1, None)
+        h.wait()
+        assert calls == ["rs", "ag"] and torch.equal(flat, torch.arange(6, dtype=torch.float32))
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,62 @@
+"""K1 inside the model (configs[1] forward, B 8): tile ORDER x operand-row layout x cache hints, profiling build.
+
+  rows   tm = token-major lane rows (B, S, heads * 36) from the library GEMM;  hm = head-major (heads, B, S, 36) from
+         wm2f_token_linear_fwd(out_group = 36)
+  mode   0 = heads innermost (4 tiles x 8 heads resident per XCD); 800 = SLAB order (heads outermost: the XCD's 32 workgroups
+         walk one (image, head) slab together); 801 / 802 / 803 = slab order + non-temporal operand loads / output stores / both
+
+Only in the model is the launch fed from HBM (kbench launches find their operands in L2 / Infinity Cache).
+Usage: python tools/k1_slab_inmodel.py [--cases tm:0,hm:0,hm:800,...] [--iters 10] [--rounds 2]
+Under rocprofv3 --pmc: one case, --rounds 1 --iters 3.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from weed_instance_segmentation_amd import _lib, modeling, ops  # noqa: E402
+
+_lib.use_profiling_library()
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", default="tm:0,hm:0,hm:800,hm:801,hm:802,hm:803")
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--rounds", type=int, default=2)
+ap.add_argument("--batch", type=int, default=8)
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+model = bench.build_model().to(dev).eval()
+x = torch.randn(args.batch, 3, 1024, 1024, device=dev)
+ref_out = None
+for rnd in range(args.rounds):
+    for case in args.cases.split(","):
+        rows, mode = case.split(":")
+        modeling.HEAD_MAJOR_ROWS = rows == "hm"
+        if mode != "0":
+            os.environ["WM2F_K1_MODE"] = mode
+        else:
+            os.environ.pop("WM2F_K1_MODE", None)
+        with torch.no_grad():
+            for _ in range(3):
+                out = model(pixel_values=x)
+            torch.cuda.synchronize()
+            t = ops.KernelTimer()
+            ops.set_kernel_timer(t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                out = model(pixel_values=x)
+            e1.record()
+            torch.cuda.synchronize()
+            ops.set_kernel_timer(None)
+        logits = out.masks_queries_logits.float()
+        if ref_out is None:
+            ref_out = logits.clone()
+        err = float((logits - ref_out).abs().max() / ref_out.abs().max())
+        print(json.dumps({"rows": rows, "mode": int(mode), "k1_in_model_us": round(t.summary()["msdeform_fused_fwd"][1], 2),
+                          "step_ms": round(e0.elapsed_time(e1) / args.iters, 3), "rel_diff_vs_first_case": err}), flush=True)

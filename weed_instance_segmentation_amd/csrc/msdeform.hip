@@ -445,7 +445,7 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
     if (const char* e = getenv("WM2F_K1_MODE")) smode = atoi(e);          // profiling build: 200 strip order, 300 round-1 loader schedule
 #endif
     if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, row,
-                                     head_stride, 1 | (value_hm ? 2 : 0)))
+                                     head_stride, 1 | (value_hm ? 2 : 0) | ((head_major & 4) ? 4 : 0)))
       return rc;
   }
   if (!handled) {

@@ -624,8 +624,9 @@ struct StreamGeom {
   QuadGeom q;
   int n_logical, per_xcd, wg_per_xcd;
   float inv_heads, inv_ntiles, inv_tiles_x;
-  // a workgroup's next tile is `wg_per_xcd` ids further: (step_t tiles, step_h heads) with heads innermost
-  int step_t, step_h;
+  // a workgroup's next tile is `wg_per_xcd` ids further: (step_t tiles, step_h heads) with heads innermost -- or, in SLAB
+  // order (tiles innermost: id = (image * heads + head) * n_tiles + tile), step_h slabs and step_t = (step_ty, step_tx) tiles
+  int step_t, step_h, step_tx, step_ty;
   // work order of the tiles of one image: vertical strips `strip_w` tiles wide, walked row by row (0 = plain raster).
   // An XCD holds 32 workgroups = 4 tiles x 8 heads at a time and its L2 (4 MiB) about three tiles' windows, so in
   // raster order the 10 halo rows a tile row shares with the next one are long gone when that row comes round
@@ -729,6 +730,14 @@ template <int ORDER>
 __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int heads) {
   TileWalk w;
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
+  if (ORDER == 3) {  // slab order: the tiles of one (image, head) slab are consecutive ids
+    const int bh = div_small(id, n_tiles, sg.inv_ntiles);
+    w.tile = id - bh * n_tiles;
+    w.b = div_small(bh, heads, sg.inv_heads);
+    w.h = bh - w.b * heads;
+    walk_xy<0>(w, sg);
+    return w;
+  }
   const int bt = div_small(id, heads, sg.inv_heads);
   w.h = id - bt * heads;
   w.b = div_small(bt, n_tiles, sg.inv_ntiles);
@@ -742,6 +751,26 @@ __device__ __forceinline__ TileWalk walk_init(int id, const StreamGeom& sg, int 
 template <int ORDER>
 __device__ __forceinline__ void walk_step(TileWalk& w, const StreamGeom& sg, int heads) {
   const int n_tiles = sg.q.tiles_x * sg.q.tiles_y;
+  if (ORDER == 3) {  // tile = ty * tiles_x + tx stays true throughout: a wrap of the tile index is a wrap of ty
+    w.tile += sg.step_t;
+    w.tx += sg.step_tx;
+    w.ty += sg.step_ty;
+    w.h += sg.step_h;
+    if (w.tx >= sg.q.tiles_x) {
+      w.tx -= sg.q.tiles_x;
+      ++w.ty;
+    }
+    if (w.tile >= n_tiles) {
+      w.tile -= n_tiles;
+      w.ty -= sg.q.tiles_y;
+      ++w.h;
+    }
+    while (w.h >= heads) {
+      w.h -= heads;
+      ++w.b;
+    }
+    return;
+  }
   int adv = sg.step_t;
   w.h += sg.step_h;
   if (w.h >= heads) {
@@ -935,7 +964,13 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     StreamGeom sg, int S, int Q, int heads) {
   constexpr int D = 32, NL = 3, P = 4;
   constexpr bool kLanes = FUSED && (OPT & 1) != 0, kSched1 = (OPT & 2) == 0, kStrips = (OPT & 4) != 0;
-  constexpr int kOrder = (OPT & 16) ? 2 : (kStrips ? 1 : 0);
+  constexpr int kOrder = (OPT & 128) ? 3 : (OPT & 16) ? 2 : (kStrips ? 1 : 0);
+  // OPT bit 7: SLAB order -- heads outermost.  An XCD's 32 workgroups walk the tiles of ONE (image, head) slab together
+  // (2.75 MB of value at config 2: it stays in the XCD's 4 MiB L2, so the window halos -- 3.6 x the slab at L2 level -- are
+  // fetched from HBM once) before the next head; needs head-major operand rows, otherwise a token's 1152-byte row is fetched
+  // once per head.  Bits 8 / 9: non-temporal hint on the operand-row loads / the output stores (streams that must not evict
+  // the slab).
+  constexpr int kOpAux = (OPT & 256) ? 2 : WM2F_OP_AUX, kStAux = (OPT & 512) ? 2 : WM2F_ST_AUX;
   constexpr bool kAllFull = EXACT && (OPT & 8) != 0;  // level sides are multiples of the tile: every tile has the full query counts
   constexpr int kLoaderWave0 = SCfg<CH>::GW, kGW = SCfg<CH>::GW, kPB = SCfg<CH>::PB, kSplit = SCfg<CH>::SPLIT;
   static_assert(SYNC == 0 || CH == 8, "the flag-synchronised form exists for the full-head kernel only");
@@ -1188,19 +1223,19 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         // b_row is the HEAD stride of the lane-major array here (144 B inside a 1152-B token row, or a whole (B, Q, 36)
         // slab when the rows are stored head-major)
         const int off = (int)__umul24((unsigned)q, (unsigned)a_row) + t.h * b_row + j * 36;
-        const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, WM2F_OP_AUX));
-        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, WM2F_OP_AUX));
+        const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, kOpAux));
+        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, kOpAux));
         o.lc[t2][0] = make_float2(A.x, A.y);
         o.lc[t2][1] = make_float2(A.z, A.w);
         o.lc[t2][2] = make_float2(Bq.x, Bq.y);
         o.wt[t2][0] = Bq.z;
         o.wt[t2][1] = Bq.w;
-        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 32, 0, WM2F_OP_AUX));
+        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 32, 0, kOpAux));
       } else {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-          o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, WM2F_OP_AUX));
-          o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, WM2F_OP_AUX));
+          o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, kOpAux));
+          o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, kOpAux));
         }
       }
     }
@@ -1353,8 +1388,8 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         }
       }
       const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4) + cur.hh * 64) : kOobOffset;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, WM2F_ST_AUX);
-      if (CH == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, WM2F_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, kStAux);
+      if (CH == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, kStAux);
     }
     WM2F_SSTAMP(9, 0);
   }
@@ -1504,6 +1539,16 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.inv_tiles_x = 1.f / (float)g.tiles_x;
   sg.step_t = sg.wg_per_xcd / (heads * split);
   sg.step_h = sg.wg_per_xcd % (heads * split);
+  sg.step_tx = sg.step_ty = 0;
+  // slab order (lanes bit 2; profiling build: modes 800-803, bit 0 / 1 = non-temporal operand loads / output stores)
+  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 803));
+  if (slab) {
+    const int n_tiles = g.tiles_x * g.tiles_y;
+    sg.step_h = sg.wg_per_xcd / n_tiles;
+    sg.step_t = sg.wg_per_xcd % n_tiles;
+    sg.step_ty = sg.step_t / g.tiles_x;
+    sg.step_tx = sg.step_t % g.tiles_x;
+  }
   // tile work order inside an image: plain raster; mode 200 = 2-wide vertical strips (see StreamGeom; A/B measurement:
   // 169 against 165 us -- the seams a strip order saves were not what the kernel waits for)
   sg.strip_w = (mode == 200 && g.tiles_x >= 2) ? 2 : 0;
@@ -1521,6 +1566,14 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   const bool ln = FUSED && (lanes & 1) != 0;
   auto kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 0>;
   if (all_full) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 8>;
+  if constexpr (FUSED) if (slab) {
+    kfn = all_full ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 1 + 128>;
+#ifdef WM2F_PROFILING
+    if (mode == 801 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 256>;
+    if (mode == 802 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 512>;
+    if (mode == 803 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 256 + 512>;
+#endif
+  }
   int threads = SCfg<8>::THREADS;
   if (!exact) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 0>;
   if (half) {

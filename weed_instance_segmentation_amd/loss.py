@@ -15,7 +15,6 @@ the default provider draws on the device.
 """
 from __future__ import annotations
 
-import os
 
 from typing import Sequence
 
@@ -85,9 +84,9 @@ class Mask2FormerLoss(nn.Module):
         self.importance_sample_ratio = config.importance_sample_ratio
         self.batched_levels = True  # loss_masks_all_levels; False = one pass per level (kept for A/B and tests)
         # mask losses on the matched queries' rows recomputed by one einsum (matched_row_logits) instead of the dense
-        # predictions; WM2F_MATCHED_ROW_MASKS=0 (or this attribute) restores the dense route for A/B and tests
-        self.matched_row_masks = os.environ.get("WM2F_MATCHED_ROW_MASKS", "1") != "0"
-        self.sort_matcher_points = os.environ.get("WM2F_SORT_MATCHER_POINTS", "1") != "0"  # see match()
+        # predictions; this attribute = False restores the dense route (A/B runs and tests)
+        self.matched_row_masks = True
+        self.sort_matcher_points = True  # see match()
         self.cost_class, self.cost_mask, self.cost_dice = config.class_weight, config.mask_weight, config.dice_weight
         self.world_size_fn = None  # set by parallel.DataParallelEngine: all-reduces num_masks (HF:781-794)
 
@@ -201,7 +200,9 @@ class Mask2FormerLoss(nn.Module):
         NL = len(order)
         dev = pix.device
         counts = [int(s.numel()) for s, _ in indices[order[0]]]
-        t_max = max(max(counts), 1)
+        # whole multiples of 4 rows per level: the hand-written K3 backward wants Q % 4 == 0 (an odd count would silently take
+        # the library bmm pair); the extra rows are zero embeddings that no index points at
+        t_max = (max(max(counts), 1) + 3) // 4 * 4
         b_idx = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
         t_idx = torch.cat([torch.arange(c) for c in counts]).to(dev)
         q_idx = torch.stack([torch.cat([s for s, _ in indices[lvl]]) for lvl in order]).to(dev)  # (NL, M)
@@ -288,6 +289,12 @@ class Mask2FormerLoss(nn.Module):
         batched = self.batched_levels and same_m and NL <= 16
         if batched:
             rows = matched_rows if (matched_rows is not None and self.matched_row_masks and all_masks[0].is_cuda) else None
+            m_total = sum(int(s.numel()) for s, _ in indices[order[0]])
+            if rows is not None and NL * m_total >= 65536:
+                # the matched-row route folds the levels into ONE map list of NL * M rows, and the point samplers carry the
+                # row in grid.y (< 65536): beyond that (33+ fully matched 200-query images per rank at 10 levels) the dense
+                # route, whose limit is per level, runs instead
+                rows = None
             lm_all, ld_all = self.loss_masks_all_levels(all_masks, tgt, offsets, indices, num_masks, order, provider, rows=rows)
             lc_all = self.loss_labels_all_levels(all_classes, cls, offsets, indices, order)
         for n, lvl in enumerate(order):

@@ -213,7 +213,8 @@ def k1_lanes_applies(level_hw, n_tokens: int, head_dim: int, n_points: int, batc
     return batch * n_tokens < (1 << 24) and batch * n_tokens * row < 0x7fffffff and batch * n_tokens * heads * 128 < 0x7fffffff
 
 
-def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int, head_major: bool = False, value_head_major: bool = False):
+def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int, head_major: bool = False, value_head_major: bool = False,
+                               slab_order: bool = False):
     """Inference K1 fed by ONE merged projection whose rows are in lane-major order (include/wm2f.h,
     wm2f_msdeform_fused_lanes_fwd): lanes (B,Q,heads*36), or head-major (heads,B,Q,36) -- what token_linear(out_group=36)
     writes and the kernel reads in fewer cache lines.  Streaming kernel only -- check `k1_lanes_applies` first; a shape it
@@ -232,7 +233,8 @@ def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int, head_major: b
     lv = host_i32([x for hw in level_hw for x in hw])
     with torch.cuda.device(value.device):
         check(_timed("msdeform_fused_fwd", value, lambda: load().wm2f_msdeform_fused_lanes_fwd(
-            _p(value), _p(lanes), _p(out), lv, B, S, Q, H, D, 3, 4, WM2F_F32, (1 if head_major else 0) | (2 if value_head_major else 0), _stream(value))),
+            _p(value), _p(lanes), _p(out), lv, B, S, Q, H, D, 3, 4, WM2F_F32, (1 if head_major else 0) | (2 if value_head_major else 0) | (4 if slab_order else 0),
+            _stream(value))),
             "wm2f_msdeform_fused_lanes_fwd")
     return out
 

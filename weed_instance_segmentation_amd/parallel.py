@@ -14,13 +14,16 @@ the path needs when the image batch is sharded over GPUs:
 
 Two forms of the bucket exchange (`exchange=`):
   "all_reduce"      one `all_reduce(SUM)` per bucket (default; RCCL picks ring / direct by size);
-  "reduce_scatter"  `reduce_scatter_tensor` + `all_gather_into_tensor` per bucket -- the two halves of an all-reduce as
-                    separate collectives, each moving S/N per peer pair over all 7 xGMI links at once; the
-                    mean is taken on the 1/N shard between the two.  Unmeasured on hardware (no multi-GPU box in the
-                    build loop); same result as "all_reduce" (tests).
+  "reduce_scatter"  `reduce_scatter_tensor` + `all_gather_into_tensor` per bucket, both IN PLACE on the flat bucket (the
+                    rank's shard is a view of it) -- the two halves of an all-reduce as separate collectives, each moving
+                    S/N per peer pair over all 7 xGMI links at once; the mean is taken on the 1/N shard between
+                    the two.  The same code runs under gloo (tests/test_parallel_cpu.py executes exactly these two
+                    collectives on CPU tensors) and RCCL; on RCCL / xGMI it is UNMEASURED (no multi-GPU box in the build
+                    loop) -- experimental until the driver's scaling run has covered it.
 
-Works with any backend (`nccl` == RCCL on ROCm; `gloo` for the tests: CPU tensors directly, GPU tensors staged through
-host memory, so that two ranks can share ONE GPU in tests/test_parallel_gpu.py -- RCCL refuses two ranks on a device).
+Works with any backend (`nccl` == RCCL on ROCm; `gloo` for the tests: CPU tensors directly, GPU tensors through a host
+copy of the bucket -- the same collectives on that copy -- so that two ranks can share ONE GPU in
+tests/test_parallel_gpu.py; RCCL refuses two ranks on a device).
 """
 from __future__ import annotations
 
@@ -36,13 +39,14 @@ class _Done:
         return True
 
 
-def _host_staged(group) -> bool:
-    return dist.is_initialized() and dist.get_backend(group) == "gloo"
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """A GPU tensor on a gloo group goes through a host copy (tests only); CPU tensors and RCCL take the collective directly."""
+    return t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
 
 
 def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
     """SUM all-reduce of `t` in place.  gloo + a GPU tensor: staged through host memory (tests only)."""
-    if t.is_cuda and _host_staged(group):
+    if _host_staged(t, group):
         h = t.detach().cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
@@ -52,7 +56,7 @@ def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
 
 
 def broadcast_from(t: torch.Tensor, src: int = 0, group=None):
-    if t.is_cuda and _host_staged(group):
+    if _host_staged(t, group):
         h = t.detach().cpu()
         dist.broadcast(h, src=src, group=group)
         t.copy_(h)
@@ -62,24 +66,24 @@ def broadcast_from(t: torch.Tensor, src: int = 0, group=None):
 
 class _ScatterGather:
     """reduce_scatter_tensor -> mean on the shard -> all_gather_into_tensor, as one waitable exchange of a flat bucket
-    (its length is a multiple of the world size).  Backends without these collectives (gloo) take the all-reduce."""
+    (its length is a multiple of the world size; both collectives in place: the rank's shard is a view of the bucket).
+    A GPU bucket on a gloo group (tests: two ranks on one card) runs the same two collectives on a host copy."""
 
     def __init__(self, flat, world, group):
         self.flat, self.world, self.group = flat, world, group
-        self.native = not _host_staged(group)
+        self.buf = flat.detach().cpu() if _host_staged(flat, group) else flat
         rank = dist.get_rank(group)
-        n = flat.numel() // world
-        self.shard = flat[rank * n:(rank + 1) * n]
-        self.work = (dist.reduce_scatter_tensor(self.shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-                     if self.native else all_reduce_sum(flat, group))
+        n = self.buf.numel() // world
+        assert n * world == self.buf.numel(), "bucket length must be a multiple of the world size"
+        self.shard = self.buf[rank * n:(rank + 1) * n]
+        self.work = dist.reduce_scatter_tensor(self.shard, self.buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
     def wait(self):
         self.work.wait()
-        if self.native:
-            self.shard.div_(self.world)
-            dist.all_gather_into_tensor(self.flat, self.shard, group=self.group)
-        else:
-            self.flat.div_(self.world)
+        self.shard.div_(self.world)
+        dist.all_gather_into_tensor(self.buf, self.shard, group=self.group)
+        if self.buf is not self.flat:
+            self.flat.copy_(self.buf)
         return True
 
 
