@@ -94,38 +94,40 @@ int wm2f_msdeform_fused_packed_fwd(const void* value, const void* packed, void* 
                                    const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L,
                                    int P, int dtype, int margin, void* stream);
 
-/* The same for rows in LANE-MAJOR order -- a free choice of the row order of the merged Linear that writes them, made for
- * the kernel's loads: per token and head, the four sampling-point slots j = 0..3 (the kernel's lanes) one after the other,
- * each as 9 floats [x y of level 0 | x y of level 1 | x y of level 2 | logit of level 0, 1, 2]:
- *   lanes (B, Q, heads * 4 * 9):  lanes[.., h*36 + j*9 + 2*l + {0,1}] = offsets[.., h, l, j, {x,y}],
- *                                 lanes[.., h*36 + j*9 + 6 + l]       = logits[.., h, l*4 + j]
- * A lane then fetches its 36 contiguous bytes per query (3 loads, quad footprint 144 B) instead of 6 loads scattered over
- * the 1152-byte row.  Streaming kernel only (D = 32, P = 4, L = 3 with sides 1:2:4 coarse first, Q == S); any other shape
- * returns WM2F_EUNSUPPORTED (use the [offsets | logits] form).  * head_major bit 0 = 0: lanes is (B, Q, heads, 36); 1: (heads, B, Q, 36) -- a head's rows of consecutive tokens contiguous, which
- * the kernel reads in 1.1 instead of 1.9 cache lines per (token, head) (wm2f_token_linear_fwd with out_group = 36 writes
- * that layout): 143 against 157 us launched back to back with the rows in cache, no difference behind the GEMM that
- * wrote them.  head_major bit 1: `value` is stored (heads, B, S, 32) instead of (B, S, heads, 32) (what
- * wm2f_token_linear_fwd with out_group = 32 writes): a head's window rows become contiguous runs. */
+/* The same for rows in the kernel's RECORD order -- a free choice of the row order of the merged Linear that writes them
+ * (ops.k1_lane_order), made for the kernel's loads.  Per token and head 36 floats = 144 bytes, in 16-byte pieces; lane j of
+ * a query's quad owns sampling-point slot j of every level:
+ *   rec[ 4 j + {0,1,2,3}]      = offsets[.., h, level 0, j, {x,y}], offsets[.., h, level 1, j, {x,y}]
+ *   rec[16 + 4 j + {0,1,2,3}]  = offsets[.., h, level 2, j, {x,y}], logits[.., h, 0*4 + j], logits[.., h, 1*4 + j]
+ *   rec[32 + j]                = logits[.., h, 2*4 + j]
+ * A lane fetches two aligned 16-byte pieces and one dword per query (3 loads inside one 144-byte record) instead of 6 loads
+ * scattered over the token's 1152-byte row.  Streaming kernel only (D = 32, P = 4, L = 3, Q == S, levels coarse first with
+ * sides 1:2:4); any other shape returns WM2F_EUNSUPPORTED (use the [offsets | logits] form).  `head_major` is a bit set:
+ *   bit 0  lanes is (heads, B, Q, 36) instead of (B, Q, heads, 36): a head's records of consecutive tokens are contiguous
+ *          (what wm2f_token_linear_fwd with out_group = 36 writes);
+ *   bit 1  `value` is stored (heads, B, S, 32) instead of (B, S, heads, 32) (out_group = 32);
+ *   bit 2  SLAB order: the tiles are walked heads-outermost, so that the workgroups of an XCD share ONE (image, head) slab
+ *          of `value` (2.75 MB at config 2) in its 4 MiB L2 and the window halos (3.6 x the slab at L2 level) come from HBM
+ *          once.  Meant for bit 0 = 1 (with token-major records every 1152-byte row would be fetched once per head).
+ *          Measured in the model: HBM traffic 1.29 x -> 1.005 x the algorithmic bytes, 156 -> 136 us.
+ * The result does not depend on any of the bits (tests: bit-identical). */
 int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lanes, void* out, const int32_t* level_hw, int B, int S,
                                   int Q, int heads, int D, int L, int P, int dtype, int head_major, void* stream);
 
-/* Same two operations with the kernel variant exposed (A/B measurement of kernels whose OUTPUTS ARE ALL VALID):
+/* Same two operations with the kernel choice exposed, so that the two fall-back kernels can be held to the golden vectors
+ * on shapes `auto` gives to the first:
  *   fused   0: a = loc, b = attn_w, ref unused      1: a = offsets, b = logits, ref as above
- *   variant 0: auto (tries 4, 3, 2, 1 in that order)
+ *   variant 0: auto (tries 4, 2, 1 in that order)
  *           1: direct gather (any D)
- *           2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4);  62: the same in slab-major work order
- *           3: phased quad kernel (3 levels with sides 1:2:4 coarse first, P = 4, D = 32, margin 4)
- *           4: streaming quad kernel (same shapes; persistent workgroups + loader waves), one workgroup per CU
- *           8: the same in its half-head form: a workgroup gathers one 16-channel half of a head, two workgroups
- *              share a CU (measured slower: twice the L2 requests)
- *           5: streaming kernel with per-window flags instead of workgroup barriers
- *           6: streaming quad kernel walking the tiles of an image in 2-wide vertical strips (4, 5: raster order)
- *           7: streaming quad kernel with the earlier loader schedule (coarse window of tile k+1 requested under the
- *              mid gather of tile k instead of behind its last barrier)
+ *           2: LDS-window kernel (D = 32, P = 4, Q == S, L <= 4)
+ *           4: streaming quad kernel (3 levels coarse first whose sides about double, P = 4, D = 32, Q == S; persistent
+ *              workgroups + loader waves), one workgroup per CU
  *   margin  window margin in pixels for the LDS-window kernel; sampling points farther than that
  *           from their reference point take a slow path (results never depend on it).
- * Any other variant returns WM2F_EUNSUPPORTED: timing ablations and stamped builds live in the separate profiling
- * library (include/wm2f_prof.h), never in libwm2f.so.  wm2f_msdeform_fwd / _fused_fwd are variant 0, margin 4. */
+ * Any other variant returns WM2F_EUNSUPPORTED: superseded kernels (phased quads, half-head form), measured negatives
+ * (flags instead of barriers, strip order, the round-1 loader schedule), timing ablations and stamped builds live in the
+ * separate profiling library (include/wm2f_prof.h), never in libwm2f.so.  wm2f_msdeform_fwd / _fused_fwd are variant 0,
+ * margin 4. */
 int wm2f_msdeform_fwd_v(const void* value, const void* a, const void* b, const void* ref, void* out,
                         const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P,
                         int dtype, int fused, int variant, int margin, void* stream);
@@ -272,6 +274,21 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
 int wm2f_token_linear_fwd(const void* x, const void* w, const void* bias, const void* residual, const void* ln_gamma,
                           const void* ln_beta, const void* pos, void* out, void* out_plus_pos, int64_t M, int K, int N, int relu,
                           int64_t pos_rows, float eps, int out_group, void* stream);
+
+/* wm2f_token_wgrad_bf16: the weight / bias gradient of such a Linear (the backward autograd derives for nn.Linear; train
+ *                        step of HF:1036-1103 under bf16 autocast):  dw (N, K) fp32 = dy (M, N)^T . x (M, K),
+ *                        db (N) fp32 = column sums of dy (NULL: skipped); dy, x bf16 row-major, fp32 accumulation on the bf16
+ *                        matrix cores.  Split over the M = batch x tokens contraction with one fp32 partial tile per
+ *                        workgroup in `workspace` (wm2f_token_wgrad_workspace(M, N, K) bytes), added in split order by a
+ *                        second kernel: deterministic, no atomics.  HBM-bound (each operand read once).  N % 8 == 0,
+ *                        K % 8 == 0, operands below 2 GiB, pointers 16-byte aligned. */
+int64_t wm2f_token_wgrad_workspace(int64_t M, int N, int K);
+int wm2f_token_wgrad_bf16(const void* dy, const void* x, void* dw, void* db, void* workspace, int64_t M, int N, int K,
+                          void* stream);
+/* The same with fp32 operands (the fp32 train step) on the fp32 matrix cores: exact fp32 products, MFMA-bound
+ * (2 M N K flop at 157 TFLOP/s).  N % 4 == 0, K % 4 == 0; same workspace function. */
+int wm2f_token_wgrad_f32(const void* dy, const void* x, void* dw, void* db, void* workspace, int64_t M, int N, int K,
+                         void* stream);
 /* wm2f_tokens_to_nchw: out (B, C, HW) = tokens (B, S, C) rows [start, start + HW) transposed per image -- the
  *                      `hidden[:, start:start+hw].transpose(1, 2).reshape(B, C, h, w)` of HF:1384-1391. */
 int wm2f_tokens_to_nchw(const void* tokens, void* out, int B, int S, int C, int start, int HW, void* stream);

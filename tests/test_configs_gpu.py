@@ -216,44 +216,137 @@ def _train_step_losses(model, x, ml, cl, seed=3):
 
 def test_config1_resnet50_1024_fp32_batch8_forward_properties():
     """BASELINE.json configs[1]: synthetic 1024 x 1024 3-class, ResNet-50, 100 queries, fp32 forward-only, batch 8 -- the
-    bench workload.  Size-independent properties of the batch-8 forward: image i alone gives image i of the batch, the
-    runs agree to round-off, the level-resolution mask route equals the full-resolution route.  (Against the oracle at this
-    size: bench.py's cpu_baseline leg, 2 images, every run.)"""
+    bench workload.  (Against the oracle at this size: bench.py's cpu_baseline leg, 2 images, every run.)
+    Run to run: STRICT.  Everything behind the backbone -- pixel decoder (K1, token GEMMs, fused passes, library GEMMs /
+    convolutions) and transformer decoder (K2, K3, mask bits) -- is bit-identical between two calls on identical backbone
+    features, and so are two whole forwards once the libraries have settled on their kernels (the FIRST call of a process
+    may run other convolution solvers than the later ones: reported below, not asserted).
+    Size-independent properties that legitimately change the rounding (other GEMM shapes / another summation order): image i
+    alone against image i of the batch, the level-resolution mask route against the full-resolution one -- compared per
+    query, because a logit within rounding of the threshold may flip a mask bit (module docstring)."""
     _need_gpu()
     from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
     torch.manual_seed(0)
     model = Mask2FormerForUniversalSegmentation(Mask2FormerConfig(num_labels=3, num_queries=100)).cuda().eval()
     x = torch.randn(8, 3, 1024, 1024, generator=torch.Generator().manual_seed(1)).cuda()
+    plm = model.model.pixel_level_module
+    feats = []
+    hook = plm.encoder.register_forward_hook(lambda m, i, o: feats.append([t.clone() for t in o]))
     with torch.no_grad():
+        first = model(pixel_values=x)
         a = model(pixel_values=x)
         b = model(pixel_values=x)
+    hook.remove()
+    assert a.masks_queries_logits.shape == (8, 100, 256, 256) and torch.isfinite(a.masks_queries_logits).all()
+    same = lambda u, v: all(torch.equal(p, q) for p, q in zip(u, v))
+    first_differs = not same(feats[0], feats[1])
+    backbone_stable = same(feats[1], feats[2])
+    print(f"config1: backbone features call 1 vs call 2 {'DIFFER' if first_differs else 'equal'}; call 2 vs call 3 "
+          f"{'equal' if backbone_stable else 'DIFFER'}")
+    # (1) identical backbone features -> bit-identical pixel decoder + transformer decoder, twice
+    real_encoder = plm.encoder
+
+    class _Cached(torch.nn.Module):
+        channels = getattr(real_encoder, "channels", None)
+
+        def forward(self, _x):
+            return [t.clone() for t in feats[1]]
+
+    plm.encoder = _Cached()
+    try:
+        with torch.no_grad():
+            c = model(pixel_values=x)
+            d = model(pixel_values=x)
+    finally:
+        plm.encoder = real_encoder
+    assert torch.equal(c.masks_queries_logits, d.masks_queries_logits) and torch.equal(c.class_queries_logits, d.class_queries_logits)
+    assert torch.equal(c.masks_queries_logits, a.masks_queries_logits)  # the cached features ARE call a's
+    # (2) whole forwards, second against third call: strict whenever the backbone's own outputs repeated
+    if backbone_stable:
+        assert torch.equal(a.masks_queries_logits, b.masks_queries_logits) and torch.equal(a.class_queries_logits, b.class_queries_logits)
+    scale = a.masks_queries_logits.abs().max().item()
+    with torch.no_grad():
         one = model(pixel_values=x[5:6])
         full = model(pixel_values=x, output_auxiliary_logits=True)  # every prediction at the mask-feature resolution
-    assert a.masks_queries_logits.shape == (8, 100, 256, 256) and torch.isfinite(a.masks_queries_logits).all()
-    scale = a.masks_queries_logits.abs().max().item()
-    # Run to run, image alone vs in the batch, level-resolution vs full-resolution masks: per query, because a mask bit
-    # at the threshold may flip (module docstring) -- and it does even run to run: the library convolutions / GEMMs around
-    # the hand-written kernels (which are deterministic: tests/test_fullsize_gpu.py) are not bit-reproducible at this size
-    # (observed 4e-5 of the logit range between the first and the second call).
-    for other, sl in ((b.masks_queries_logits, a.masks_queries_logits), (one.masks_queries_logits[0], a.masks_queries_logits[5]),
-                      (full.masks_queries_logits, a.masks_queries_logits)):
+    pairs = [(one.masks_queries_logits[0], a.masks_queries_logits[5]), (full.masks_queries_logits, a.masks_queries_logits),
+             (first.masks_queries_logits, a.masks_queries_logits)]
+    if not backbone_stable:
+        pairs.append((b.masks_queries_logits, a.masks_queries_logits))
+    for other, sl in pairs:
         per_q = (other - sl).abs().flatten(-2).amax(-1) / scale
         assert (per_q < 1e-4).float().mean().item() > 0.97, per_q.max()
-    torch.testing.assert_close(a.class_queries_logits, b.class_queries_logits, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(a.class_queries_logits, first.class_queries_logits, rtol=1e-3, atol=1e-3)
+
+
+def _grad_step(model, x, ml, cl, amp, seed=3):
+    """One full train-mode step (forward, loss, backward) with fixed sampled points; returns (loss, {name: grad})."""
+    from weed_instance_segmentation_amd.loss import DevicePointProvider
+    prov = DevicePointProvider("cuda", torch.Generator(device="cuda").manual_seed(seed))
+    model.train()
+    try:
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out = model(pixel_values=x, mask_labels=ml, class_labels=cl, point_provider=prov)
+        out.loss.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        return float(out.loss.detach()), grads
+    finally:
+        model.eval()
+        model.zero_grad(set_to_none=True)
 
 
 def test_config2_resnet50_1024_bf16_train_step_batch16():
     """BASELINE.json configs[2]: the configs[1] model, bf16 autocast, full train step (Hungarian matching + mask / dice /
-    class loss over 10 levels + backward through K1 / K2 / K3), batch 16 on one GPU: finite loss and gradients, and the
-    bf16 loss within 5 % of the fp32 step on the same batch and the same sampled points."""
+    class loss over 10 levels + backward through K1 / K2 / K3), batch 16 on one GPU, against the SAME step in fp32 on the
+    same batch and the same sampled points: finite loss and gradients, the bf16 loss within 5 % of the fp32 loss, and the
+    parameter gradients tensor by tensor -- direction (cosine) and size (norm ratio) -- not only the scalar.  bf16 rounds every
+    stock-op activation to 8 bits and may flip a Hungarian assignment or a mask bit, so single tensors may disagree; the
+    bounds are on the distribution over the ~650 parameter tensors, weighted towards the ones that carry the gradient."""
     _need_gpu()
     from weed_instance_segmentation_amd import Mask2FormerConfig, Mask2FormerForUniversalSegmentation
     torch.manual_seed(0)
     model = Mask2FormerForUniversalSegmentation(Mask2FormerConfig(num_labels=3, num_queries=100)).cuda()
     x = torch.randn(16, 3, 1024, 1024, generator=torch.Generator().manual_seed(1)).cuda()
     ml, cl = _synthetic_labels(16, 1024, 1024)
-    l32, l16 = _train_step_losses(model, x, ml, cl)
-    assert abs(l16 - l32) / abs(l32) < 5e-2, (l32, l16)
+    l32, g32 = _grad_step(model, x, ml, cl, amp=False)
+    l16, g16 = _grad_step(model, x, ml, cl, amp=True)
+    assert np.isfinite(l16) and abs(l16 - l32) / abs(l32) < 5e-2, (l32, l16)
+    assert g32.keys() == g16.keys() and len(g16) > 100
+    names, cos, ratio, weight = [], [], [], []
+    for n in g32:
+        a, b = g32[n].flatten().double(), g16[n].flatten().double()
+        assert torch.isfinite(b).all(), n
+        na, nb = float(a.norm()), float(b.norm())
+        if na == 0.0:
+            continue
+        names.append(n)
+        cos.append(float(a @ b) / max(na * nb, 1e-300))
+        ratio.append(nb / na)
+        weight.append(na)
+    cos, ratio, weight = np.array(cos), np.array(ratio), np.array(weight)
+    backbone = np.array([n.startswith("model.pixel_level_module.encoder.") for n in names])
+
+    def stats(sel, label):
+        e = weight[sel] ** 2 / (weight[sel] ** 2).sum()  # share of this group's squared gradient norm
+        c, r = cos[sel], ratio[sel]
+        worst = np.argsort(c)[:5]
+        nm = [n for n, s_ in zip(names, sel) if s_]
+        print(f"config2 bf16 vs fp32 gradients, {label} ({int(sel.sum())} tensors): cosine median {np.median(c):.4f}, "
+              f"energy-weighted mean {float((e * c).sum()):.4f}, min {c.min():.4f}; norm ratio median {np.median(r):.3f}, energy-weighted "
+              f"{float((e * r).sum()):.3f}; energy in tensors with cosine < 0.5: {float(e[c < 0.5].sum()):.2e}; worst: "
+              + ", ".join(f"{nm[i]} cos {c[i]:.2f} energy {e[i]:.1e}" for i in worst))
+        return float((e * c).sum()), float(np.median(c)), float(e[c < 0.5].sum()), float((e * r).sum()), float(np.median(r))
+
+    # Everything behind the backbone -- pixel decoder (K1 and its token Linears), transformer decoder (K2, K3), heads: the
+    # gradient there has passed this package's backward kernels and a few stock Linears only.  Strict.
+    ew, med, lost, rw, rmed = stats(~backbone, "pixel decoder + transformer decoder + heads")
+    assert ew > 0.99 and med > 0.995 and lost < 1e-3, (ew, med, lost)
+    assert 0.95 < rw < 1.05 and 0.95 < rmed < 1.05, (rw, rmed)
+    # The ResNet-50 backbone (stock convolutions and train-mode BatchNorm in bf16): its first stages see a gradient that has passed
+    # ~50 bf16 convolution backwards and batch statistics of 16 images -- direction is largely lost there in ANY bf16-autocast run
+    # of this model (first measurement: stem weight cosine 0.09 with 1.4 % of the whole gradient's energy).  Reported; loose bound.
+    ew_b, med_b, lost_b, rw_b, _ = stats(backbone, "ResNet-50 backbone (stock ops)")
+    assert ew_b > 0.8 and med_b > 0.95 and 0.8 < rw_b < 1.25, (ew_b, med_b, rw_b)
 
 
 def _swin_config(embed_dim, depths, heads, window, num_queries, num_labels=3, **over):

@@ -75,11 +75,12 @@ def test_k1_fused_prologue(ops):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant,margin", [(1, 4), (2, 4), (2, 0), (62, 1), (0, 7)])
+@pytest.mark.parametrize("variant,margin", [(1, 4), (2, 4), (2, 0), (4, 4), (0, 7)])
 @pytest.mark.parametrize("tag", ["toy", "rect"])
 def test_k1_variants_golden(ops, tag, variant, margin):
-    """Direct-gather and LDS-window kernels give the same answer; the window margin never changes it
-    (the golden locations are spread far outside any margin, so the slow path is exercised)."""
+    """The three kernels the library runs -- direct gather (1), LDS windows (2), streaming quads (4; what `auto` picks
+    here) -- give the same answer; the window margin never changes it (the golden locations are spread far outside any
+    margin, so the slow path is exercised)."""
     g = load_golden(f"k1_msdeform_{tag}.npz")
     out = ops.ms_deform_attn_variant(dev(T(g["value"])), g["level_hw"].tolist(), dev(T(g["loc"])), dev(T(g["w"])),
                                      variant=variant, margin=margin)
@@ -105,7 +106,7 @@ def test_k1_tiled_local_offsets(ops, shapes, B, fused):
     loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
     aw = torch.softmax(logits, -1).view(B, S, H, L, P)
     ref = O.msdeform_attn_core(value, shapes, loc, aw)
-    for margin, variant in ((4, 2), (2, 2), (4, 62)):
+    for margin, variant in ((4, 2), (2, 2)):
         if fused:
             out = ops.ms_deform_attn_variant(dev(value), shapes, dev(off), dev(logits), dev(ref_pts), fused=True,
                                              variant=variant, margin=margin)
@@ -120,11 +121,11 @@ def test_k1_tiled_local_offsets(ops, shapes, B, fused):
                                       ([(32, 32), (64, 64), (128, 128)], 6)])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("spread", ["local", "wide"])
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", [4])
 def test_k1_quad_kernel(ops, shapes, B, fused, spread, variant):
-    """Phased quad kernel (variant 3) and its streaming form (variant 4: persistent workgroups + loader waves; what
-    `auto` picks for the encoder's 1:2:4 pyramids): ragged edge tiles, several tiles per workgroup,
-    offsets inside the window margin (fast path) and far outside it (every point on the slow path)."""
+    """The streaming quad kernel (variant 4: persistent workgroups + loader waves; what `auto` picks for the encoder's
+    1:2:4 pyramids) through the two-array entry points: ragged edge tiles, several tiles per workgroup, offsets inside
+    the window margin (fast path) and far outside it (every point on the slow path)."""
     H, D, L, P = 8, 32, 3, 4
     g = torch.Generator().manual_seed(21)
     S = sum(h * w for h, w in shapes)
@@ -146,11 +147,18 @@ def test_k1_quad_kernel(ops, shapes, B, fused, spread, variant):
 
 
 def test_k1_quad_kernel_refuses_other_pyramids(ops):
+    """A forced kernel choice that does not apply raises; so do the superseded kernels and A/B variants, which exist in
+    the profiling build only (include/wm2f_prof.h)."""
     from weed_instance_segmentation_amd._lib import Wm2fError
-    shapes = [(7, 9), (13, 17), (25, 33)]
-    value, loc, w = _rand_k1(1, shapes, 8, 32, 3)
+    shapes = [(12, 20), (24, 40)]
+    value, loc, w = _rand_k1(1, shapes, 8, 32, 2)
     with pytest.raises(Wm2fError):
-        ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(w), variant=3)
+        ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(w), variant=4)
+    shapes = [(4, 4), (8, 8), (16, 16)]
+    value, loc, w = _rand_k1(1, shapes, 8, 32, 3)
+    for variant in (3, 5, 6, 7, 8, 62, 44, 74):
+        with pytest.raises(Wm2fError):
+            ops.ms_deform_attn_variant(dev(value), shapes, dev(loc), dev(w), variant=variant)
 
 
 @pytest.mark.parametrize("shapes,D", [([(8, 8), (16, 16), (32, 32)], 32), ([(5, 7), (10, 14), (20, 28)], 32),
@@ -188,11 +196,8 @@ def test_k1_fused_lanes(ops, shapes, B, spread):
     value = torch.randn(B, S, H, D, generator=g)
     off = torch.randn(B, S, H, L, P, 2, generator=g) * spread
     logits = torch.randn(B, S, H, L * P, generator=g) * 2
-    lanes = torch.empty(B, S, H, P, 9)
-    for l in range(L):
-        lanes[..., 2 * l] = off[:, :, :, l, :, 0]
-        lanes[..., 2 * l + 1] = off[:, :, :, l, :, 1]
-        lanes[..., 6 + l] = logits.view(B, S, H, L, P)[:, :, :, l, :]
+    lanes = ops.k1_lane_rows(off, logits).view(B, S, H, 36)  # the record order of include/wm2f.h
+    assert torch.equal(lanes[0, 5, 2, 4 * 1 + 2:4 * 1 + 4], off[0, 5, 2, 1, 1]) and lanes[0, 5, 2, 32 + 3] == logits[0, 5, 2, 2 * 4 + 3]
     ref_pts = O.reference_points(shapes, 1)[0].contiguous()
     norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.long)
     loc = ref_pts[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
@@ -206,13 +211,13 @@ def test_k1_fused_lanes(ops, shapes, B, spread):
     out2 = ops.ms_deform_attn_fused_packed(dev(value), shapes, dev(packed), dev(ref_pts), H, L, P)
     assert torch.equal(out, out2)
     # the same rows stored head-major, (heads, B, S, 36): same loads per lane from other addresses, so identical bits
-    out3 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.permute(2, 0, 1, 3, 4).reshape(H, B, S, 36).contiguous()), H, head_major=True)
+    out3 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.permute(2, 0, 1, 3).contiguous()), H, head_major=True)
     assert torch.equal(out, out3)
     # value stored head-major, (heads, B, S, 32): the loaders read the same pixels through other strides
     out4 = ops.ms_deform_attn_fused_lanes(dev(value.permute(2, 0, 1, 3).contiguous()), shapes, dev(lanes.reshape(B, S, H * 36)), H, value_head_major=True)
     assert torch.equal(out, out4)
     # slab order (heads outermost: an XCD's workgroups walk one (image, head) slab together): another work order, same bits
-    out5 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.permute(2, 0, 1, 3, 4).reshape(H, B, S, 36).contiguous()), H,
+    out5 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.permute(2, 0, 1, 3).contiguous()), H,
                                           head_major=True, slab_order=True)
     assert torch.equal(out, out5)
     out6 = ops.ms_deform_attn_fused_lanes(dev(value), shapes, dev(lanes.reshape(B, S, H * 36)), H, slab_order=True)
@@ -779,6 +784,78 @@ def test_token_linear_fused_epilogues(ops, M, K, N, relu, ln, res, pos):
             got = ops.token_linear(dev(xi), dev(wi), dev(bi), relu=relu, out_group=G)
             assert got.shape == (N // G, M, G)
             assert torch.equal(got.cpu(), want.view(M, N // G, G).permute(1, 0, 2))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (5000, 96, 256), (4097, 192, 256), (3000, 1024, 256), (3000, 256, 1024),
+                                   (70, 288, 256), (63, 256, 256), (20000, 256, 256), (130, 8, 8), (777, 520, 264)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_token_wgrad(ops, M, N, K, dtype):
+    """wm2f_token_wgrad_bf16 / _f32: dW = dy^T x and db = column sums of dy for the token Linears of the pixel decoder (bf16
+    or fp32 operands, fp32 accumulation, partial tiles added in split order) against the same products in fp64 on the CPU.
+    bf16 products are exact in fp32 and fp32 products are rounded once, so the summation order (and that rounding) is all
+    that separates the two: a few fp32 ulps of sqrt(M) x the largest term.  Exact small-integer operands pin the transposed fragment reads (ds_read_b64_tr_b16), the XOR swizzle of the LDS
+    image and the accumulator layout bit for bit; ragged token counts, feature counts that are not multiples of the 256-wide
+    block (zero-filled through the buffer range check) and several column blocks (N or K = 1024) are included; two runs
+    give identical bits (no atomics)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).to(dtype)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    assert ops.token_wgrad_applies(dev(dy), dev(x))
+    dw, db = ops.token_wgrad(dev(dy), dev(x))
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    tol = 4e-6 * math.sqrt(M) * 3.0 * 3.0  # |dy|, |x| reach ~3 sigma
+    assert dw.shape == (N, K) and dw.dtype == torch.float32 and db.shape == (N,)
+    assert (dw.cpu().double() - ref_w).abs().max().item() <= tol, (dw.cpu().double() - ref_w).abs().max().item()
+    assert (db.cpu().double() - ref_b).abs().max().item() <= tol
+    dw2, db2 = ops.token_wgrad(dev(dy), dev(x))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # exact integers: every product and every partial sum is exact in fp32
+    dyi = torch.randint(-3, 4, (M, N), generator=g).to(dtype)
+    xi = torch.randint(-3, 4, (M, K), generator=g).to(dtype)
+    dwi, dbi = ops.token_wgrad(dev(dyi), dev(xi))
+    assert torch.equal(dwi.cpu(), (dyi.float().t() @ xi.float())) and torch.equal(dbi.cpu(), dyi.float().sum(0))
+    dwn, dbn = ops.token_wgrad(dev(dyi), dev(xi), want_bias=False)
+    assert dbn is None and torch.equal(dwn, dwi)
+
+
+def test_linear_tokens_autograd_under_bf16_autocast(ops):
+    """ops.linear_tokens (what the pixel decoder's encoder layers call in training): under bf16 autocast the same output as
+    F.linear bit for bit, the same input gradient, and weight / bias gradients that agree with F.linear's autograd to bf16
+    rounding (the library's come back rounded to bf16, the kernel's in fp32 -- compared against fp64); without autocast or
+    without autograd it IS F.linear."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 700, 256, generator=g)
+    w = (torch.randn(192, 256, generator=g) * 0.05)
+    b = torch.randn(192, generator=g)
+    go = torch.randn(3, 700, 192, generator=g)
+    res = {}
+    for name in ("wm2f", "torch"):
+        xv, wv, bv = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ops.linear_tokens(xv, wv, bv) if name == "wm2f" else torch.nn.functional.linear(xv, wv, bv)
+        y.backward(dev(go).to(y.dtype))
+        res[name] = (y.detach(), xv.grad, wv.grad, bv.grad)
+    (ya, gxa, gwa, gba), (yb, gxb, gwb, gbb) = res["wm2f"], res["torch"]
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb)
+    assert gwa.dtype == torch.float32 and gxa.dtype == torch.float32
+    torch.testing.assert_close(gxa, gxb, rtol=2e-2, atol=2e-2)
+    gob, xb16 = go.to(torch.bfloat16).double().reshape(-1, 192), x.to(torch.bfloat16).double().reshape(-1, 256)
+    ref_w, ref_b = gob.t() @ xb16, gob.sum(0)
+    assert (gwa.cpu().double() - ref_w).abs().max().item() <= 1e-4 * ref_w.abs().max().item()
+    assert (gba.cpu().double() - ref_b).abs().max().item() <= 1e-4 * ref_b.abs().max().item()
+    assert (gwb.cpu().double() - ref_w).abs().max().item() <= 2e-2 * ref_w.abs().max().item()  # the library's, for scale
+    # fp32 training (no autocast): the same output bits, gradients to fp32 round-off of the fp64 products
+    xv, wv, bv = dev(x).requires_grad_(), dev(w).requires_grad_(), dev(b).requires_grad_()
+    y32 = ops.linear_tokens(xv, wv, bv)
+    assert y32.dtype == torch.float32 and torch.equal(y32, torch.nn.functional.linear(dev(x), dev(w), dev(b)))
+    y32.backward(dev(go))
+    rw, rb = go.double().reshape(-1, 192).t() @ x.double().reshape(-1, 256), go.double().reshape(-1, 192).sum(0)
+    assert (wv.grad.cpu().double() - rw).abs().max().item() <= 1e-5 * rw.abs().max().item()
+    assert (bv.grad.cpu().double() - rb).abs().max().item() <= 1e-5 * rb.abs().max().item()
+    torch.testing.assert_close(xv.grad.cpu().double(), go.double() @ w.double(), rtol=1e-4, atol=1e-4)
+    with torch.no_grad():  # no autograd: plain F.linear
+        assert torch.equal(ops.linear_tokens(dev(x), dev(w), dev(b)), torch.nn.functional.linear(dev(x), dev(w), dev(b)))
 
 
 @pytest.mark.parametrize("shapes,B", [([(25, 42), (50, 84), (100, 167)], 1), ([(7, 11), (13, 21), (25, 42)], 2),

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", type=int, default=73)
     ap.add_argument("--lanes", action="store_true", help="variant 74 on the lane-major operand rows (the model's inference path): sets WM2F_K1_STAMP=1 for the profiling library")
+    ap.add_argument("--slab", type=int, default=0, help="with --lanes: WM2F_K1_MODE of a stamped slab-order build (807) on head-major rows")
     ap.add_argument("--init", action="store_true", help="the module's initial offset pattern instead of uniform offsets in [-4, 4]")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,15 +40,13 @@ def main():
     refl = ref[:, None, :].expand(S, L, 2).contiguous()
     if a.lanes:
         os.environ["WM2F_K1_STAMP"] = "1"
-        lanes = torch.empty(B, S, H, P, 9, device=dev)
-        for l in range(L):
-            lanes[..., 2 * l] = off[:, :, :, l, :, 0]
-            lanes[..., 2 * l + 1] = off[:, :, :, l, :, 1]
-            lanes[..., 6 + l] = logits.view(B, S, H, L, P)[:, :, :, l, :]
-        lanes = lanes.reshape(B, S, H * 36).contiguous()
+        lanes = ops.k1_lane_rows(off, logits)
+        if a.slab:
+            os.environ["WM2F_K1_MODE"] = str(a.slab)
+            lanes = lanes.view(B, S, H, 36).permute(2, 0, 1, 3).contiguous()
     for _ in range(3):
         if a.lanes:
-            ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H)
+            ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H, head_major=bool(a.slab))
         else:
             ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=a.variant)
     torch.cuda.synchronize()

@@ -87,12 +87,7 @@ def main():
                 res[f"k1_fused_variant{variant}_margin{margin}"] = r
         if "k1l" in only:  # fused forms: [offsets | logits] rows vs lane-major rows vs the round-1 loader schedule, interleaved rounds
             packed = torch.cat([off.reshape(B, S, -1), logits.reshape(B, S, -1)], -1).contiguous()
-            lanes = torch.empty(B, S, H, P, 9, device=dev)
-            for l in range(L):
-                lanes[..., 2 * l] = off[:, :, :, l, :, 0]
-                lanes[..., 2 * l + 1] = off[:, :, :, l, :, 1]
-                lanes[..., 6 + l] = logits.view(B, S, H, L, P)[:, :, :, l, :]
-            lanes = lanes.reshape(B, S, H * 36).contiguous()
+            lanes = ops.k1_lane_rows(off, logits)
             fns = {"packed_rows": lambda: ops.ms_deform_attn_fused_packed(value, shapes, packed, refl, H, L, P),
                    "lane_major_rows": lambda: ops.ms_deform_attn_fused_lanes(value, shapes, lanes, H),
                    "two_arrays": lambda: ops.ms_deform_attn_variant(value, shapes, off, logits, refl, fused=True, variant=4),

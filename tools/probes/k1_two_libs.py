@@ -44,57 +44,6 @@ def main():
             res.setdefault(name, []).append(round(ts[len(ts) // 2], 2))
     for k, v in res.items():
         print(json.dumps({"lib": k, "k1_fused_packed_init_operands_med_us": v}))
-    if "--lanes" in sys.argv:  # the LAST library's lane-major entry point (what the model runs) on the same operands
-        lib = ctypes.CDLL(libs[-1])
-        f = lib.wm2f_msdeform_fused_lanes_fwd
-        f.restype = ctypes.c_int
-        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 8 + [ctypes.c_void_p]
-        row = torch.zeros(H, P, 9)
-        for l in range(L):
-            row[:, :, 2 * l:2 * l + 2] = off[:, l]  # (H, P, 2)
-        rows = row.reshape(-1).to(dev).expand(B, S, -1).contiguous()
-        call = lambda: f(value.data_ptr(), rows.data_ptr(), out.data_ptr(), hw, B, S, S, H, D, L, P, 0, st)
-        meds = []
-        for rep in range(7):
-            for _ in range(5):
-                assert call() == 0
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(iters):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); call(); b.record(); torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b) * 1e3)
-            ts.sort()
-            meds.append(round(ts[len(ts) // 2], 2))
-        print(json.dumps({"lib": libs[-1], "k1_fused_lanes_init_operands_med_us": meds}))
-        import os
-        if os.environ.get("WM2F_K1_HEAD_MAJOR") == "1":  # profiling build: the same rows stored (heads, B, S, 36); random values in both
-            torch.manual_seed(1)
-            tm = (torch.randn(B, S, H, 36, device=dev) * 2).contiguous()
-            hm = tm.permute(2, 0, 1, 3).contiguous()
-            o2 = torch.empty_like(out)
-            os.environ["WM2F_K1_HEAD_MAJOR"] = "0"
-            assert f(value.data_ptr(), tm.data_ptr(), out.data_ptr(), hw, B, S, S, H, D, L, P, 0, st) == 0
-            os.environ["WM2F_K1_HEAD_MAJOR"] = "1"
-            assert f(value.data_ptr(), hm.data_ptr(), o2.data_ptr(), hw, B, S, S, H, D, L, P, 0, st) == 0
-            torch.cuda.synchronize()
-            print(json.dumps({"head_major_equals_token_major": bool(torch.equal(out, o2))}))
-            res2 = {"token_major": [], "head_major": []}
-            for rep in range(7):
-                for name, arr, flag in (("token_major", rows, "0"), ("head_major", rows.view(B, S, H, 36).permute(2, 0, 1, 3).contiguous(), "1")):
-                    os.environ["WM2F_K1_HEAD_MAJOR"] = flag
-                    call = lambda: f(value.data_ptr(), arr.data_ptr(), out.data_ptr(), hw, B, S, S, H, D, L, P, 0, st)
-                    for _ in range(5):
-                        assert call() == 0
-                    torch.cuda.synchronize()
-                    ts = []
-                    for _ in range(iters):
-                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        a.record(); call(); b.record(); torch.cuda.synchronize()
-                        ts.append(a.elapsed_time(b) * 1e3)
-                    ts.sort()
-                    res2[name].append(round(ts[len(ts) // 2], 2))
-            print(json.dumps(res2))
     if "--variants" in sys.argv:  # the LAST library's streaming-kernel variants (two-array fused form) on the same operands
         lib = ctypes.CDLL(libs[-1])
         f = lib.wm2f_msdeform_fwd_v

@@ -66,6 +66,9 @@ SIGNATURES = {
     "wm2f_bias_act": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_add_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _I, c_int64, c_float, _P]),
     "wm2f_token_linear_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _I, _I, _I, c_int64, c_float, _I, _P]),
+    "wm2f_token_wgrad_workspace": (c_int64, [c_int64, _I, _I]),
+    "wm2f_token_wgrad_bf16": (c_int, [_P, _P, _P, _P, _P, c_int64, _I, _I, _P]),
+    "wm2f_token_wgrad_f32": (c_int, [_P, _P, _P, _P, _P, c_int64, _I, _I, _P]),
     "wm2f_tokens_to_nchw": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_group_norm_tokens": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, c_float, _P]),
     "wm2f_resize_bilinear": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),

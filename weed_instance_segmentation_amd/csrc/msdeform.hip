@@ -276,16 +276,15 @@ static LaunchGeom geom(int B, int Q, int heads, int D) {
   return g;
 }
 
-// variant: 0 = auto (phased quad kernel, else LDS-window kernel, else direct gather), 1 = direct,
-//          2 = LDS-window kernel only; 12/22/32/42/52/62 = its timing ablations (invalid outputs
-//          except 62 = slab-major work order); 3 = phased quad kernel only; 13/23/43 = its ablations;
-//          4 = streaming quad kernel only (persistent workgroups + loader waves); 44 = without LDS reads;
-//          5 = streaming kernel with per-window flags instead of workgroup barriers
-//          6 = streaming kernel walking the tiles in 2-wide vertical strips (default: raster)
-//          7 = streaming kernel with the round-1 loader schedule (coarse(k+1) requested under the mid gather of tile k)
-//          8 = streaming kernel in its half-head form (two 77-KiB workgroups per CU, each a 16-channel half of a head;
-//              measured slower than the full-head form 4); 44 / 74 ablation / stamped build of the full-head form,
-//              84 the stamped half-head build (profiling library)
+// variant (production library): 0 = auto (streaming quad kernel, else LDS-window kernel, else direct gather), 1 = direct
+//          gather only, 2 = LDS-window kernel only, 4 = streaming quad kernel only -- the three kernels the library runs,
+//          selectable so that the two fall-backs can be held to the golden vectors on shapes `auto` gives to the first.
+// Profiling build only (libwm2f_prof.so, include/wm2f_prof.h) -- measured negatives, ablations, stamped builds:
+//          3 = phased quad kernel (superseded by the streaming form), 13/23/43 its ablations, 73 stamped;
+//          12/22/32/42/52 LDS-window ablations, 62 = LDS windows in slab-major work order;
+//          5 = streaming kernel with per-window flags instead of workgroup barriers, 6 = tiles in 2-wide vertical strips,
+//          7 = round-1 loader schedule, 8 = half-head form (two 77-KiB workgroups per CU), 44 without LDS reads,
+//          74 / 84 stamped full-head / half-head builds
 template <bool FUSED>
 static int launch_fwd(const void* value, const void* a, const void* b, const void* ref, void* out,
                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
@@ -297,12 +296,9 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
   LevelInfo lv;
   if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
 #ifndef WM2F_PROFILING
-  // the production library launches only kernels whose outputs are valid: 0 auto, 1 direct gather, 2 LDS windows,
-  // 3 phased quads, 4 streaming quads, 5 streaming with flags, 6 / 7 streaming in strip tile order / with the round-1
-  // loader schedule, 8 half-head streaming, 62 LDS windows in slab-major order
-  if (!(variant >= 0 && variant <= 8) && variant != 62) {
-    set_error("%s: variant %d is a timing ablation / stamped build: profiling library only (libwm2f_prof.so, "
-              "include/wm2f_prof.h)", who, variant);
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4) {
+    set_error("%s: variant %d is a superseded kernel, a timing ablation or a stamped build: profiling library only "
+              "(libwm2f_prof.so, include/wm2f_prof.h)", who, variant);
     return WM2F_EUNSUPPORTED;
   }
 #endif
@@ -317,17 +313,17 @@ static int launch_fwd(const void* value, const void* a, const void* b, const voi
       return WM2F_EUNSUPPORTED;
     }
   }
-  if (D == 32 && margin == 4 && (variant == 0 || variant % 10 == 3)) {
+#ifdef WM2F_PROFILING
+  if (D == 32 && margin == 4 && variant % 10 == 3) {
     bool handled = false;
     if (int rc = launch_quad<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled,
                                     variant / 10, 0, 0))
       return rc;
     if (handled) return WM2F_OK;
-    if (variant != 0) {
-      set_error("%s: the phased quad kernel needs D=32, P=4, Q==S and 3 levels with sides 1:2:4, coarse first", who);
-      return WM2F_EUNSUPPORTED;
-    }
+    set_error("%s: the phased quad kernel needs D=32, P=4, Q==S and 3 levels with sides 1:2:4, coarse first", who);
+    return WM2F_EUNSUPPORTED;
   }
+#endif
   if (variant != 1 && D == 32) {
     bool handled = false;
     if (int rc = launch_tiled<FUSED>(value, a, b, out, level_hw, B, S, Q, heads, L, P, margin,
@@ -405,12 +401,6 @@ extern "C" int wm2f_msdeform_fused_packed_fwd(const void* value, const void* pac
                                      &handled, 0, row, row))
       return rc;
   }
-  if (D == 32 && margin == 4 && !handled) {
-    const float* a = (const float*)packed;
-    if (int rc = launch_quad<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, stream, who,
-                                   &handled, 0, row, row))
-      return rc;
-  }
   if (D == 32 && !handled) {
     const float* a = (const float*)packed;
     if (int rc = launch_tiled<true>(value, a, a + heads * L * P * 2, out, level_hw, B, S, Q, heads, L, P, margin, 512,
@@ -445,7 +435,7 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
     if (const char* e = getenv("WM2F_K1_MODE")) smode = atoi(e);          // profiling build: 200 strip order, 300 round-1 loader schedule
 #endif
     if (int rc = launch_stream<true>(value, lanes, lanes, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, smode, row,
-                                     head_stride, 1 | (value_hm ? 2 : 0) | ((head_major & 4) ? 4 : 0)))
+                                     head_stride, 1 | (value_hm ? 2 : 0) | (head_major & 4)))
       return rc;
   }
   if (!handled) {

@@ -45,7 +45,8 @@ namespace wm2f {
 namespace {
 
 constexpr int kQF = 16, kQM = 4;
-constexpr int kThreads = 512, kWavesQ = kThreads / kWave, kQuads = kThreads / 4, kPasses = 3;
+constexpr int kThreads = 512, kWavesQ = kThreads / kWave, kPasses = 3;
+[[maybe_unused]] constexpr int kQuads = kThreads / 4;
 template <int LV> struct Win {
   static constexpr int side = (kQF >> (2 - LV)) + 2 * kQM + 2;  // 14, 18, 26
   static constexpr int npix = side * side;
@@ -316,6 +317,7 @@ __device__ __forceinline__ void quad_point_slow(float4& acc, const float* __rest
   if (yb && xr) fma4s(acc, aw * fy1 * fx1, ld4g(p00 + (int64_t)(Wl + 1) * row_stride));
 }
 
+#ifdef WM2F_PROFILING  // the phased kernel: superseded by the streaming form below; kept as the measured baseline of it
 // FUSED = false: a = loc (B,Q,heads,3,4,2), b = attn_w (B,Q,heads,3,4)
 // FUSED = true : a = raw offsets, b = raw logits; reference points are recomputed from the query grid.
 // MODE 0 = the kernel; 1 = staging only, 2 = gather only, 4 = gather without LDS reads: timing
@@ -549,6 +551,8 @@ __global__ __launch_bounds__(kThreads) void msdeform_quad_fwd_kernel(const float
   WM2F_STAMP(13);
 }
 
+
+#endif  // WM2F_PROFILING (phased kernel)
 
 // =====================================================================================================
 // Streaming form of the kernel above: persistent workgroups, two loader waves.
@@ -971,6 +975,10 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
   // once per head.  Bits 8 / 9: non-temporal hint on the operand-row loads / the output stores (streams that must not evict
   // the slab).
   constexpr int kOpAux = (OPT & 256) ? 2 : WM2F_OP_AUX, kStAux = (OPT & 512) ? 2 : WM2F_ST_AUX;
+  // Lane rows: the 36 floats of a (token, head) record come in 16-byte ALIGNED pieces -- [x0 y0 x1 y1] of lanes 0..3, then
+  // [x2 y2 w0 w1] of lanes 0..3, then w2 of lanes 0..3 (include/wm2f.h) -- so that a lane's two dwordx4 loads are 16-byte
+  // aligned (nine consecutive floats per lane, a 36-byte lane stride, measured 1 % slower in the model).
+  constexpr bool kAligned = kLanes;
   constexpr bool kAllFull = EXACT && (OPT & 8) != 0;  // level sides are multiples of the tile: every tile has the full query counts
   constexpr int kLoaderWave0 = SCfg<CH>::GW, kGW = SCfg<CH>::GW, kPB = SCfg<CH>::PB, kSplit = SCfg<CH>::SPLIT;
   static_assert(SYNC == 0 || CH == 8, "the flag-synchronised form exists for the full-head kernel only");
@@ -1198,7 +1206,6 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         }
       }
     }
-    const int ah = (t.h * (NL * P * 2) + j * 2) * 4, bh = (t.h * (NL * P) + j) * 4;
 #pragma unroll
     for (int t2 = 0; t2 < kPasses; ++t2) {
       int q;
@@ -1212,25 +1219,31 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         o.valid[t2] = pc.valid(t2);
       }
       o.qrow[t2] = q;
+    }
+    const int ah = (o.h * (NL * P * 2) + j * 2) * 4, bh = (o.h * (NL * P) + j) * 4;
+#pragma unroll
+    for (int t2 = 0; t2 < kPasses; ++t2) {
+      const int q = o.qrow[t2];
       const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
       const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
       if (kLanes) {
-        // lane-major rows (wm2f_msdeform_fused_lanes_fwd): the 9 numbers of lane j of head h are consecutive --
-        // [x y] of its point on levels 0, 1, 2, then its three logits -- so a pass is 3 loads whose quad footprint is one
-        // 144-byte run, instead of 6 loads scattered over the token's 1152-byte row (16 quads x 6 loads x 8 waves queued
+        // lane rows (wm2f_msdeform_fused_lanes_fwd): the 36 numbers of head h form one 144-byte record -- a pass is 3 loads
+        // (two 16-byte aligned dwordx4, one dword) whose quad footprint lies inside that record, instead of 6 loads
+        // scattered over the token's 1152-byte row (16 quads x 6 loads x 8 waves queued
         // in the texture-address unit behind the loaders' traffic: the per-wave stamps showed 3.0k cycles for the older and
         // 5.5k for the younger wave of each SIMD in this fetch)
         // b_row is the HEAD stride of the lane-major array here (144 B inside a 1152-B token row, or a whole (B, Q, 36)
         // slab when the rows are stored head-major)
-        const int off = (int)__umul24((unsigned)q, (unsigned)a_row) + t.h * b_row + j * 36;
+        const int rec = (int)__umul24((unsigned)q, (unsigned)a_row) + o.h * b_row;
+        const int off = rec + (kAligned ? j * 16 : j * 36);
         const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, kOpAux));
-        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 16, 0, kOpAux));
+        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + (kAligned ? 64 : 16), 0, kOpAux));
         o.lc[t2][0] = make_float2(A.x, A.y);
         o.lc[t2][1] = make_float2(A.z, A.w);
         o.lc[t2][2] = make_float2(Bq.x, Bq.y);
         o.wt[t2][0] = Bq.z;
         o.wt[t2][1] = Bq.w;
-        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 32, 0, kOpAux));
+        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, kAligned ? rec + 128 + j * 4 : off + 32, 0, kOpAux));
       } else {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -1354,8 +1367,13 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         const float* ap = lm ? a_in + (int64_t)cur.qrow[t] * g.a_qstride + (int64_t)cur.h * g.b_qstride
                              : a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
         const float* bp = lm ? ap : b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
+        // where point k2 of level l keeps its x (y follows) and its logit inside the 36-float record
+        auto xy_at = [&](int k2, int l) __attribute__((always_inline)) {
+          return kAligned ? (l < 2 ? k2 * 4 + 2 * l : 16 + k2 * 4) : (lm ? k2 * 9 + 2 * l : (l * P + k2) * 2);
+        };
         auto logit_at = [&](int i) __attribute__((always_inline)) {  // i = l * P + k2
-          return lm ? bp[(i & 3) * 9 + 6 + (i >> 2)] : bp[i];
+          const int k2 = i & 3, l = i >> 2;
+          return kAligned ? bp[l < 2 ? 16 + k2 * 4 + 2 + l : 32 + k2] : (lm ? bp[k2 * 9 + 6 + l] : bp[i]);
         };
         float refx = 0.f, refy = 0.f, sm_max = 0.f, sm_inv = 1.f;
         if (FUSED && todo) {  // re-derive what the fast path no longer holds in registers
@@ -1372,7 +1390,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
           const int k2 = i / 3, l = i - k2 * 3;
           const int Wl = l == 2 ? g.W[2] : (l == 1 ? g.W[1] : g.W[0]), Hl = l == 2 ? g.H[2] : (l == 1 ? g.H[1] : g.H[0]);
           const int st_l = l == 0 ? g.start[0] : (l == 1 ? g.start[1] : g.start[2]);
-          const float lx = lm ? ap[k2 * 9 + 2 * l] : ap[(l * P + k2) * 2], ly = lm ? ap[k2 * 9 + 2 * l + 1] : ap[(l * P + k2) * 2 + 1];
+          const float lx = ap[xy_at(k2, l)], ly = ap[xy_at(k2, l) + 1];
           float aw = logit_at(l * P + k2), x, y;
           if (FUSED) {
             aw = __expf(aw - sm_max) * sm_inv;
@@ -1398,6 +1416,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
 }  // namespace
 
 // ------------------------------------------------------------------------------------ host side
+#ifdef WM2F_PROFILING
 // Applies when: 3 levels ordered coarse -> fine with sides exactly 1 : 2 : 4, 4 points, queries == tokens.
 template <bool FUSED>
 int launch_quad(const void* value, const void* a, const void* b, void* out, const int32_t* level_hw, int B, int S, int Q,
@@ -1450,6 +1469,8 @@ template int launch_quad<false>(const void*, const void*, const void*, void*, co
 template int launch_quad<true>(const void*, const void*, const void*, void*, const int32_t*, int, int, int, int, int,
                                int, void*, const char*, bool*, int, int, int);
 
+
+#endif  // WM2F_PROFILING (launch_quad)
 
 // Streaming launch: one workgroup per CU.
 template <bool FUSED>
@@ -1541,7 +1562,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.step_h = sg.wg_per_xcd % (heads * split);
   sg.step_tx = sg.step_ty = 0;
   // slab order (lanes bit 2; profiling build: modes 800-803, bit 0 / 1 = non-temporal operand loads / output stores)
-  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 803));
+  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 807));
   if (slab) {
     const int n_tiles = g.tiles_x * g.tiles_y;
     sg.step_h = sg.wg_per_xcd / n_tiles;
@@ -1572,29 +1593,30 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
     if (mode == 801 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 256>;
     if (mode == 802 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 512>;
     if (mode == 803 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 256 + 512>;
+    if (mode == 807 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 9 + 128>;
 #endif
   }
   int threads = SCfg<8>::THREADS;
   if (!exact) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 0>;
+#ifndef WM2F_PROFILING
+  if (mode != 0) return WM2F_OK;  // every other mode is a measured negative, an ablation or a stamped build: profiling library
+#else
   if (half) {
     kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 4, true, 0>;
     threads = SCfg<4>::THREADS;
   }
-#ifdef WM2F_PROFILING
   if (mode == 4 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true, 0>;
   if (mode == 7 && exact) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 1> : msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 0>;
   if (mode == 74 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 4, true, 0>;
-#endif
   if (mode == 100 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 1, 8, true, 0>;  // flags instead of barriers
   if (mode == 200 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 4>;  // 2-wide vertical strips (A/B measurement)
-#ifdef WM2F_PROFILING
   if (mode == 200 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 5>;  // strips on the lane-major rows (in-model A/B)
   if (zorder && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 25>;  // Z-order tile walk (in-model A/B)
   if (mode == 600 && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 41>;  // younger gather waves at priority 1
   if (mode == 700 && exact && ln && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 73>;  // older gather waves at priority 1
   if (mode == 300 && exact && ln) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 3>;  // round-1 schedule on the lane-major rows
+  else if (mode == 300 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 2>;  // the round-1 loader schedule (A/B measurement)
 #endif
-  if (mode == 300 && exact) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 2>;  // the round-1 loader schedule (A/B measurement)
   hipLaunchKernelGGL(kfn, dim3(wg), dim3(threads), 0, (hipStream_t)stream, (const float*)value, (const float*)a,
                      (const float*)b, (float*)out, sg, S, Q, heads);
   hipError_t e = hipGetLastError();

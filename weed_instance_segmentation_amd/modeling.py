@@ -62,17 +62,14 @@ class Mask2FormerForUniversalSegmentationOutput:
 
 
 _POS_CACHE: dict = {}
-# Route the narrow token Linears of the pixel decoder's encoder layers (value_proj, merged offsets | logits, output_proj +
-# residual + LayerNorm) through csrc/token_gemm.hip instead of the library GEMM + the separate LayerNorm pass.  Off by
-# default: measured at config 2 the hand-written kernel is at parity with hipBLASLt on these shapes, not ahead
-# (DESIGN.md 4.9); WM2F_TOKEN_GEMM=1 turns it on for A/B runs.
-TOKEN_GEMM = os.environ.get("WM2F_TOKEN_GEMM", "0") == "1"
-# The merged offsets | logits projection of MSDeformAttn (inference) on that kernel with HEAD-major output rows,
-# (heads, B, S, 36).  Off by default: K1 alone, launched back to back, reads them 9 % faster (143 against 157 us: 1.1 instead
-# of 1.9 cache lines per (token, head), all served from L2 / Infinity Cache), but IN THE MODEL the rows come from HBM behind
-# the GEMM that wrote them and the launch takes the same 162 us either way.  WM2F_HEAD_MAJOR_ROWS=1 for A/B.
-HEAD_MAJOR_ROWS = os.environ.get("WM2F_HEAD_MAJOR_ROWS", "0") == "1"
-HEAD_MAJOR_VALUE = os.environ.get("WM2F_HEAD_MAJOR_VALUE", "0") == "1"  # the same question for the value tensor (A/B)
+# K1 inference layout.  The merged offsets | logits projection of MSDeformAttn runs on the hand-written
+# token GEMM (csrc/token_gemm.hip), whose epilogue writes the rows HEAD-major, (heads, B, S, 36), and K1 walks its tiles in
+# SLAB order (heads outermost: an XCD's workgroups share one (image, head) slab of `value` in its L2).  Together: HBM
+# traffic of a K1 launch 1.29 x -> 1.005 x its algorithmic bytes, 156 -> 138 us in the model.  Either one alone gains
+# nothing (head-major rows under the old order: round 2; slab order on token-major rows re-fetches every 1152-byte row
+# once per head).  Plain module attributes -- tools/ flip them for A/B runs; the package reads no environment.
+HEAD_MAJOR_ROWS = True
+HEAD_MAJOR_VALUE = False  # value (heads, B, S, 32) from the token GEMM too: A/B only (tools/k1_slab_inmodel.py)
 
 
 def sine_position_embedding(H: int, W: int, num_pos_feats: int, device, dtype=torch.float32, temperature=10000):
@@ -112,8 +109,8 @@ class MSDeformAttn(nn.Module):
     def _offsets_logits_weight(self, lanes: bool = False):
         """[sampling_offsets ; attention_weights] as ONE (288, 256) projection for the inference path:
         two skinny GEMMs (N = 192 and N = 96, ~15 % of the fp32 matrix peak each) become one.
-        lanes=True: the same rows in the kernel's lane-major order (wm2f_msdeform_fused_lanes_fwd): per head and point
-        slot j, [x y of level 0, 1, 2 | logit of level 0, 1, 2] -- a row permutation of the weight, nothing else."""
+        lanes=True: the same rows in the kernel's record order (ops.k1_lane_order, wm2f_msdeform_fused_lanes_fwd) -- a row
+        permutation of the weight, nothing else."""
         so, aw = self.sampling_offsets, self.attention_weights
         key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.device)
         if self._cat.get("key") != key:
@@ -122,64 +119,47 @@ class MSDeformAttn(nn.Module):
                 self._cat = dict(key=key, w=w, b=b)
                 H, L, P = self.n_heads, self.n_levels, self.n_points
                 if L == 3 and P == 4:
-                    n_off = H * L * P * 2
-                    idx = torch.empty(H, P, 9, dtype=torch.int64)
-                    for l in range(L):
-                        for xy in range(2):  # offsets row ((h * L + l) * P + j) * 2 + xy
-                            idx[:, :, 2 * l + xy] = ((torch.arange(H)[:, None] * L + l) * P + torch.arange(P)[None, :]) * 2 + xy
-                        idx[:, :, 6 + l] = n_off + torch.arange(H)[:, None] * (L * P) + l * P + torch.arange(P)[None, :]  # logits row
-                    idx = idx.reshape(-1).to(w.device)
+                    idx = ops.k1_lane_order(H).to(w.device)
                     self._cat.update(w_lanes=w[idx].contiguous(), b_lanes=b[idx].contiguous())
         if lanes:
             return self._cat["w_lanes"], self._cat["b_lanes"]
         return self._cat["w"], self._cat["b"]
 
-    def forward(self, hidden, pos, ref, level_hw, hp=None, fuse_ln=None):
-        """hidden (B,S,C); pos (S,C) shared by the batch; ref (S,L,2); hp = hidden + pos if already known.
-        fuse_ln = (residual, LayerNorm): return LayerNorm(output_proj(.) + residual) from the token-GEMM epilogue."""
+    def forward(self, hidden, pos, ref, level_hw, hp=None):
+        """hidden (B,S,C); pos (S,C) shared by the batch; ref (S,L,2); hp = hidden + pos if already known."""
         B, S, C = hidden.shape
         H, L, P = self.n_heads, self.n_levels, self.n_points
         if hp is None:
             hp = hidden + pos[None]
-        tg = (TOKEN_GEMM and not torch.is_grad_enabled() and ops.token_linear_applies(hidden, self.value_proj.weight)
-              and not torch.is_autocast_enabled("cuda"))
-        v_hm = (HEAD_MAJOR_VALUE and not torch.is_grad_enabled() and hp.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
-                and ops.token_linear_applies(hidden, self.value_proj.weight) and ops.k1_lanes_applies(level_hw, S, C // H, P, B, H))
-        if v_hm:  # A/B (DESIGN.md 9.1): value written head-major, (heads, B, S, 32), by the token GEMM
-            value = ops.token_linear(hidden, self.value_proj.weight, self.value_proj.bias, out_group=C // H)
-            w, b = self._offsets_logits_weight(lanes=True)
-            out = ops.ms_deform_attn_fused_lanes(value, level_hw, F.linear(hp, w, b), H, value_head_major=True)
-            return self.output_proj(out) if fuse_ln is None else ops.token_linear(
-                out, self.output_proj.weight, self.output_proj.bias, residual=fuse_ln[0], ln=(fuse_ln[1].weight, fuse_ln[1].bias, fuse_ln[1].eps))
-        if tg:  # the narrow token GEMMs on the hand-written fp32 MFMA kernel (csrc/token_gemm.hip)
-            value = ops.token_linear(hidden, self.value_proj.weight, self.value_proj.bias).view(B, S, H, C // H)
-        else:
-            value = self.value_proj(hidden).view(B, S, H, C // H)
         if torch.is_grad_enabled() and (hidden.requires_grad or self.value_proj.weight.requires_grad):
-            off = self.sampling_offsets(hp).view(B, S, H, L, P, 2)
-            logits = self.attention_weights(hp).view(B, S, H, L * P)
+            # (ops.linear_tokens = F.linear; under bf16 autocast its weight gradient runs on wm2f_token_wgrad_bf16)
+            lin = ops.linear_tokens
+            value = lin(hidden, self.value_proj.weight, self.value_proj.bias).view(B, S, H, C // H)
+            off = lin(hp, self.sampling_offsets.weight, self.sampling_offsets.bias).view(B, S, H, L, P, 2)
+            logits = lin(hp, self.attention_weights.weight, self.attention_weights.bias).view(B, S, H, L * P)
             norm = torch.tensor([[w, h] for h, w in level_hw], dtype=hidden.dtype, device=hidden.device)
             loc = ref[None, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
             aw = torch.softmax(logits, -1).view(B, S, H, L, P)
             out = ops.ms_deform_attn(value, level_hw, loc, aw)
+            return lin(out, self.output_proj.weight, self.output_proj.bias)
         elif ops.k1_lanes_applies(level_hw, S, C // H, P, B, H) and hp.dtype == torch.float32:
             # inference, the encoder's own shape: one merged projection with its rows in the kernel's lane order
             w, b = self._offsets_logits_weight(lanes=True)
-            if HEAD_MAJOR_ROWS and ops.token_linear_applies(hp, w):
-                # opt-in: the merged projection on the hand-written token GEMM, whose epilogue can write the rows HEAD-major --
-                # (heads, B, S, 36) -- see HEAD_MAJOR_ROWS above
-                rows = ops.token_linear(hp, w, b, out_group=36)
-                out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H, head_major=True)
+            # (under autocast the projection stays a bf16 library GEMM, as the dependency's Linear is there)
+            hm_rows = HEAD_MAJOR_ROWS and not torch.is_autocast_enabled("cuda") and ops.token_linear_applies(hp, w)
+            hm_value = HEAD_MAJOR_VALUE and hm_rows and ops.token_linear_applies(hidden, self.value_proj.weight)
+            if hm_value:
+                value = ops.token_linear(hidden, self.value_proj.weight, self.value_proj.bias, out_group=C // H)
             else:
-                rows = ops.token_linear(hp, w, b) if tg and ops.token_linear_applies(hp, w) else F.linear(hp, w, b)
-                out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H)
+                value = self.value_proj(hidden).view(B, S, H, C // H)
+            rows = ops.token_linear(hp, w, b, out_group=36) if hm_rows else F.linear(hp, w, b)
+            out = ops.ms_deform_attn_fused_lanes(value, level_hw, rows, H, head_major=hm_rows, value_head_major=hm_value,
+                                                 slab_order=hm_rows)
         else:  # inference: one merged projection; softmax + location arithmetic fused into the kernel
+            value = self.value_proj(hidden).view(B, S, H, C // H)
             w, b = self._offsets_logits_weight()
             ol = F.linear(hp, w, b)  # (B, S, 288): [offsets (H*L*P*2) | logits (H*L*P)] per token
             out = ops.ms_deform_attn_fused_packed(value, level_hw, ol, ref, H, L, P)
-        if fuse_ln is not None:  # (residual, LayerNorm module): output_proj + residual + LayerNorm in one kernel (HF:1012, :1076-1078)
-            res, ln = fuse_ln
-            return ops.token_linear(out, self.output_proj.weight, self.output_proj.bias, residual=res, ln=(ln.weight, ln.bias, ln.eps))
         return self.output_proj(out)
 
 
@@ -204,18 +184,15 @@ class PixelDecoderEncoderLayer(nn.Module):
             # bias + ReLU in the fc1 GEMM epilogue
             B_, S_, C_ = hidden.shape
             ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
-            if TOKEN_GEMM and ops.token_linear_applies(hidden, self.self_attn.output_proj.weight):
-                hidden = self.self_attn(hidden, pos, ref, level_hw, hp, fuse_ln=(hidden, ln1))
-            else:
-                a = self.self_attn(hidden, pos, ref, level_hw, hp)
-                hidden = ops.add_layernorm(a, hidden, ln1.weight, ln1.bias, ln1.eps)
+            a = self.self_attn(hidden, pos, ref, level_hw, hp)
+            hidden = ops.add_layernorm(a, hidden, ln1.weight, ln1.bias, ln1.eps)
             f = torch._addmm_activation(self.fc1.bias, hidden.reshape(B_ * S_, C_), self.fc1.weight.t(), use_gelu=False)
             f = self.fc2(f).view(B_, S_, C_)
             return ops.add_layernorm(f, hidden, ln2.weight, ln2.bias, ln2.eps, pos=pos)
         a = F.dropout(self.self_attn(hidden, pos, ref, level_hw, hp), self.dropout, self.training)
         hidden = self.self_attn_layer_norm(hidden + a)
-        f = F.dropout(F.relu(self.fc1(hidden)), self.dropout, self.training)
-        f = F.dropout(self.fc2(f), self.dropout, self.training)
+        f = F.dropout(F.relu(ops.linear_tokens(hidden, self.fc1.weight, self.fc1.bias)), self.dropout, self.training)
+        f = F.dropout(ops.linear_tokens(f, self.fc2.weight, self.fc2.bias), self.dropout, self.training)
         hidden = self.final_layer_norm(hidden + f)
         if self.training and not torch.isfinite(hidden).all():  # HF:1090-1093
             cv = torch.finfo(hidden.dtype).max - 1000
@@ -465,7 +442,7 @@ class MaskedAttentionDecoder(nn.Module):
         self.layernorm = nn.LayerNorm(config.hidden_dim)
         self.mask_predictor = MaskPredictor(config.hidden_dim, config.num_attention_heads, config.mask_feature_size)
         # switch for A/B tests of the low-resolution attention-mask route (WM2F_LOW_RES_MASKS=0 turns it off at construction)
-        self.low_res_masks = os.environ.get("WM2F_LOW_RES_MASKS", "1") != "0"
+        self.low_res_masks = True  # False: every intermediate prediction at full resolution (A/B runs and tests)
         # tests: set to a list to receive every layer's attention-mask bytes (B, Q, HW_l) in order
         self.record_attention_masks: list | None = None
 

@@ -213,6 +213,29 @@ def k1_lanes_applies(level_hw, n_tokens: int, head_dim: int, n_points: int, batc
     return batch * n_tokens < (1 << 24) and batch * n_tokens * row < 0x7fffffff and batch * n_tokens * heads * 128 < 0x7fffffff
 
 
+def k1_lane_order(heads: int) -> torch.Tensor:
+    """Row permutation that turns the [sampling_offsets ; attention_weights] projection (heads*24 offset rows, then heads*12
+    logit rows; L = 3, P = 4) into the kernel's record order (include/wm2f.h, wm2f_msdeform_fused_lanes_fwd): 36 numbers per
+    head in 16-byte pieces -- [x0 y0 x1 y1] of lanes (= point slots) 0..3, [x2 y2 w0 w1] of lanes 0..3, w2 of lanes 0..3."""
+    L, P = 3, 4
+    n_off = heads * L * P * 2
+    h = torch.arange(heads)[:, None]
+    j = torch.arange(P)[None, :]
+    off = lambda l, xy: ((h * L + l) * P + j) * 2 + xy       # (heads, P) row index of offsets[h, l, j, xy]
+    lg = lambda l: n_off + h * (L * P) + l * P + j             # (heads, P) row index of logits[h, l * P + j]
+    a = torch.stack([off(0, 0), off(0, 1), off(1, 0), off(1, 1)], -1).reshape(heads, 16)
+    b = torch.stack([off(2, 0), off(2, 1), lg(0), lg(1)], -1).reshape(heads, 16)
+    return torch.cat([a, b, lg(2)], 1).reshape(-1)
+
+
+def k1_lane_rows(offsets: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+    """(B, S, heads, 3, 4, 2) offsets and (B, S, heads, 12) logits -> (B, S, heads * 36) rows in the kernel's record order
+    (what the merged projection with its rows permuted by `k1_lane_order` writes); tests and tools build operands with it."""
+    B, S, H = offsets.shape[:3]
+    packed = torch.cat([offsets.reshape(B, S, -1), logits.reshape(B, S, -1)], -1)
+    return packed[..., k1_lane_order(H).to(packed.device)].contiguous()
+
+
 def ms_deform_attn_fused_lanes(value, level_hw, lanes, heads: int, head_major: bool = False, value_head_major: bool = False,
                                slab_order: bool = False):
     """Inference K1 fed by ONE merged projection whose rows are in lane-major order (include/wm2f.h,
@@ -662,6 +685,77 @@ def token_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu
             _p(x), _p(weight), _p(bias), _p(residual), _p(gamma), _p(beta), _p(pos), _p(out), _p(out_pos), M, K, N, 1 if relu else 0,
             pos_rows, eps, int(out_group), _stream(x))), "wm2f_token_linear_fwd")
     return (out, out_pos) if pos is not None else out
+
+
+def token_wgrad_applies(dy: torch.Tensor, x: torch.Tensor) -> bool:
+    """Shapes wm2f_token_wgrad_bf16 / _f32 are built for: both operands bf16 or both fp32 on a GPU, feature counts multiples
+    of 8, operands below 2 GiB."""
+    N, K = dy.shape[-1], x.shape[-1]
+    M = x.numel() // max(K, 1)
+    es = x.element_size()
+    return (dy.is_cuda and x.is_cuda and dy.dtype == x.dtype and x.dtype in (torch.bfloat16, torch.float32) and N % 8 == 0
+            and K % 8 == 0 and dy.numel() == M * N and M * N * es < 0x7fffffff and M * K * es < 0x7fffffff)
+
+
+def token_wgrad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool = True):
+    """Weight (and bias) gradient of a Linear over tokens: dy (..., N), x (..., K), both bf16 or both fp32 -> dw (N, K) fp32 =
+    dy^T x and db (N) fp32 = column sums of dy (None without `want_bias`).  fp32 accumulation, deterministic (include/wm2f.h)."""
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"token_wgrad: {x.dtype}")
+    dy, x = _req(dy, "dy", x.dtype), _req(x, "x", x.dtype)
+    N, K = dy.shape[-1], x.shape[-1]
+    M = x.numel() // K
+    if dy.numel() != M * N:
+        raise ValueError(f"token_wgrad: dy {tuple(dy.shape)} x {tuple(x.shape)}")
+    dw = torch.empty(N, K, device=x.device, dtype=torch.float32)
+    db = torch.empty(N, device=x.device, dtype=torch.float32) if want_bias else None
+    bf = x.dtype == torch.bfloat16
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(16, int(load().wm2f_token_wgrad_workspace(M, N, K))), device=x.device, dtype=torch.uint8)
+        fn = load().wm2f_token_wgrad_bf16 if bf else load().wm2f_token_wgrad_f32
+        check(_timed(f"token_wgrad_{'bf16' if bf else 'f32'}_N{N}_K{K}", x, lambda: fn(
+            _p(dy), _p(x), _p(dw), _p(db), _p(ws), M, N, K, _stream(x))), "wm2f_token_wgrad")
+    return dw, db
+
+
+class _TokenLinear(torch.autograd.Function):
+    """nn.Linear over tokens with the weight gradient on wm2f_token_wgrad_*: forward and input gradient are the library's GEMMs
+    (in bf16 under bf16 autocast, as autocast runs F.linear; in fp32 otherwise), dW / db come back in fp32 -- the parameters'
+    dtype -- from ONE pass over dy and x."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bf16):
+        cdt = torch.bfloat16 if bf16 else torch.float32
+        xc, wc = x.to(cdt), weight.to(cdt)
+        ctx.save_for_backward(xc, wc)
+        ctx.x_dtype, ctx.has_bias, ctx.cdt = x.dtype, bias is not None, cdt
+        return torch.nn.functional.linear(xc, wc, None if bias is None else bias.to(cdt))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xc, wc = ctx.saved_tensors
+        g = grad_out.to(ctx.cdt).contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(g, wc).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = token_wgrad(g, xc.contiguous(), want_bias=ctx.has_bias)
+        return gx, gw, gb, None
+
+
+def linear_tokens(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None) -> torch.Tensor:
+    """F.linear for the token matrices of the pixel decoder's encoder layers.  In training on a GPU (fp32, or under bf16
+    autocast) the weight-gradient product -- a 256 x 256 output with a contraction over every token of the batch, which a
+    library GEMM runs on 16 of 256 CUs -- goes to wm2f_token_wgrad_*.  Everything else is plain F.linear."""
+    amp = torch.is_autocast_enabled("cuda")
+    bf16 = amp and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    if (torch.is_grad_enabled() and x.is_cuda and weight.requires_grad and weight.dtype == torch.float32
+            and (bf16 or (not amp and x.dtype == torch.float32))
+            and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
+            and x.numel() // weight.shape[1] * max(weight.shape) * (2 if bf16 else 4) < 0x7fffffff):
+        with torch.autocast("cuda", enabled=False):
+            return _TokenLinear.apply(x, weight, bias, bf16)
+    return torch.nn.functional.linear(x, weight, bias)
 
 
 def tokens_to_nchw(tokens: torch.Tensor, start: int, h: int, w: int) -> torch.Tensor:

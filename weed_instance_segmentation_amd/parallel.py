@@ -88,7 +88,14 @@ class _ScatterGather:
 
 
 class GradBuckets:
-    """Flat gradient storage with per-bucket async exchange."""
+    """Flat gradient storage with per-bucket async exchange.
+
+    Parameters keep `.grad = None` while backward runs, so autograd hands every gradient over as the tensor it computed
+    (no per-parameter add into a zeroed buffer: 647 add launches = 8 - 11 ms of a config-2 train step, profiles/r02_train_*);
+    a post-accumulate hook collects it, and when the last gradient of a bucket has arrived the whole bucket is folded into
+    its flat storage by ONE multi-tensor copy (or add, on the later micro-steps of an accumulation window) and -- on the last
+    micro-step -- its exchange is launched.  `finish()` leaves `.grad` = the (averaged) view into the flat bucket for the
+    optimiser; `release()` (after the optimiser step) sets `.grad` back to None."""
 
     def __init__(self, params: Iterable[nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None,
                  exchange: str = "all_reduce"):
@@ -111,57 +118,99 @@ class GradBuckets:
             self._close(cur)
         self._handles: list = []
         self._hooks = []
-        if self.world > 1:
-            for bi, b in enumerate(self.buckets):
-                for p in b["params"]:
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b["params"]):
+                p.grad = None
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, pi)))
         self.sync_enabled = True
 
     def _close(self, ps):
         n = sum(p.numel() for p in ps)
         n = (n + self.world - 1) // self.world * self.world  # whole shards for the reduce-scatter form
         flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
-        off = 0
+        views, off = [], 0
         for p in ps:
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.buckets.append(dict(params=ps, flat=flat, pending=len(ps)))
+        self.buckets.append(dict(params=ps, flat=flat, views=views, fresh=[None] * len(ps), pending=len(ps), has_data=False,
+                                 sent=False))
 
-    def _make_hook(self, bi):
-        def hook(_p):
+    def _make_hook(self, bi, pi):
+        def hook(p):
             b = self.buckets[bi]
-            b["pending"] -= 1
-            if b["pending"] == 0 and self.sync_enabled:
-                self._launch(b)
+            if b["fresh"][pi] is None:
+                b["pending"] -= 1
+                b["fresh"][pi] = p.grad
+            else:  # a second backward inside one micro-step (not the engine's own use): keep the sum
+                b["fresh"][pi] = b["fresh"][pi] + p.grad
+            p.grad = None
+            if b["pending"] == 0:
+                self._fold(b)
+                if self.sync_enabled:
+                    self._launch(b)
         return hook
+
+    def _fold(self, b):
+        """This micro-step's gradients of one bucket -> its flat storage (multi-tensor copy / add); parameters that got no
+        gradient contribute zeros."""
+        got = [(v, g) for v, g in zip(b["views"], b["fresh"]) if g is not None]
+        if got:
+            vs, gs = [v for v, _ in got], [g if g.dtype == v.dtype else g.to(v.dtype) for v, g in got]
+            if b["has_data"]:
+                torch._foreach_add_(vs, gs)
+            else:
+                torch._foreach_copy_(vs, gs)
+        if not b["has_data"]:
+            for v, g in zip(b["views"], b["fresh"]):
+                if g is None:
+                    v.zero_()
+        b["has_data"] = True
+        b["fresh"] = [None] * len(b["params"])
+        b["pending"] = len(b["params"])
+        b["folded"] = True
+
+    def end_micro_step(self):
+        """After a backward that is NOT the last of its accumulation window: fold the buckets whose hooks did not all fire."""
+        for b in self.buckets:
+            if not b.get("folded"):
+                self._fold(b)
+            b["folded"] = False
 
     def _launch(self, b):
         b["sent"] = True
+        if self.world == 1:
+            return
         if self.exchange == "reduce_scatter":
             self._handles.append(_ScatterGather(b["flat"], self.world, self.group))
         else:
             self._handles.append(all_reduce_sum(b["flat"], self.group, async_op=True))
 
     def finish(self):
-        """Wait for every in-flight bucket, reduce stragglers (parameters that got no gradient this
-        step never fire their hook), and turn sums into means."""
-        if self.world > 1 and self.sync_enabled:
+        """Fold and exchange what is still outstanding (a parameter without a gradient this step never fires its hook), wait,
+        turn sums into means and hand the flat views to the parameters as `.grad`."""
+        for b in self.buckets:
+            if not b.get("folded"):
+                self._fold(b)
+            b["folded"] = False
+            if not b["sent"]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if self.world > 1 and self.exchange == "all_reduce":
             for b in self.buckets:
-                if not b.get("sent"):  # a parameter without a gradient this step: its hook never fired
-                    self._launch(b)
-            for h in self._handles:
-                h.wait()
-            if self.exchange == "all_reduce":
-                for b in self.buckets:
-                    b["flat"].div_(self.world)
+                b["flat"].div_(self.world)
         self._handles.clear()
         for b in self.buckets:
-            b["pending"] = len(b["params"])
             b["sent"] = False
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
 
-    def zero(self):
+    def release(self):
+        """After the optimiser step: `.grad` = None again (the next backward's gradients arrive as fresh tensors)."""
         for b in self.buckets:
-            b["flat"].zero_()
+            b["has_data"] = False
+            for p in b["params"]:
+                p.grad = None
 
     def nbytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
@@ -200,12 +249,11 @@ class DataParallelEngine:
         self.buckets.sync_enabled = last  # exchange only on the last micro-step of an accumulation window
         (loss / self.accumulation).backward()
         if not last:
-            for b in self.buckets.buckets:
-                b["pending"] = len(b["params"])
+            self.buckets.end_micro_step()
             return False
         self.buckets.finish()
         self.optimizer.step()
-        self.buckets.zero()
+        self.buckets.release()
         return True
 
     def train_step(self, pixel_values, mask_labels, class_labels):
