@@ -202,6 +202,15 @@ int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v, const voi
                           const void* row_open, void* out, void* lse, void* workspace,
                           int B, int heads, int Q, int N, int D, int dtype, void* stream);
 
+/* The same with bf16 operands, for the bf16-autocast configurations (BASELINE configs 2-4), where the dependency's two
+ * attention products are bf16 matrix products around an fp32 softmax (TORCHF:6578-6600 under autocast): q, k, v bf16 as the
+ * in_proj Linears emit them (no cast pass, half the K / V bytes), both products on the bf16 matrix cores with fp32
+ * accumulation, softmax / (m, l) / O in fp32, P rounded to bf16 for the second product; out (B, Q, heads*D) and lse fp32.
+ * Same mask / row_open / workspace (wm2f_masked_xattn_workspace) as the fp32 form.  Full-tile form only: D = 32,
+ * N % 16 == 0, 16-byte aligned operands -- anything else returns WM2F_EUNSUPPORTED (cast to fp32, call the form above). */
+int wm2f_masked_xattn_bf16_fwd(const void* q, const void* k, const void* v, const void* mask, const void* row_open,
+                               void* out, void* lse, void* workspace, int B, int heads, int Q, int N, int D, void* stream);
+
 /* Backward of the above (P is recomputed from q, k and lse).  grad_q is the gradient w.r.t. the
  * PRE-SCALED q; grad_q / grad_k / grad_v are overwritten.
  *   out, lse: the forward's results; grad_out (B, Q, heads*D)
@@ -211,6 +220,14 @@ int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v, const voi
                           const void* row_open, const void* out, const void* lse, const void* grad_out,
                           void* grad_q, void* grad_k, void* grad_v, void* workspace,
                           int B, int heads, int Q, int N, int D, int dtype, void* stream);
+
+/* Backward of wm2f_masked_xattn_bf16_fwd: q, k, v bf16 as saved by the forward, out / lse / grad_out fp32; grad_q fp32,
+ * grad_k / grad_v bf16 (the operands' dtype).  The five products per (key tile, query tile) on the bf16 matrix cores, p and dS
+ * in fp32 from fp32 accumulators.  Workspace: wm2f_masked_xattn_bwd_workspace.  D = 32, N % 16 == 0, Q <= 112 (one query
+ * chunk), 16-byte aligned operands; anything else returns WM2F_EUNSUPPORTED (cast to fp32, wm2f_masked_xattn_bwd). */
+int wm2f_masked_xattn_bf16_bwd(const void* q, const void* k, const void* v, const void* mask, const void* row_open,
+                               const void* out, const void* lse, const void* grad_out, void* grad_q, void* grad_k,
+                               void* grad_v, void* workspace, int B, int heads, int Q, int N, int D, void* stream);
 
 /* ---- K4: Hungarian-matcher cost matrices ------------------------------------------------------
  * Replaces Mask2FormerHungarianMatcher.forward up to (not including) the scipy solver,

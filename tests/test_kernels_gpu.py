@@ -786,6 +786,69 @@ def test_token_linear_fused_epilogues(ops, M, K, N, relu, ln, res, pos):
             assert torch.equal(got.cpu(), want.view(M, N // G, G).permute(1, 0, 2))
 
 
+@pytest.mark.parametrize("B,H,Q,N,use_mask", [(2, 8, 100, 1024, True), (1, 8, 100, 4096, True), (1, 4, 20, 16, True),
+                                              (1, 2, 130, 80, True), (2, 8, 100, 208, True), (2, 8, 100, 512, False),
+                                              (1, 8, 200, 16384, True)])
+def test_k2_bf16_forward(ops, B, H, Q, N, use_mask):
+    """wm2f_masked_xattn_bf16_fwd (bf16 q / k / v as the in_proj Linears emit them under autocast, bf16 MFMA products, fp32
+    softmax): against the oracle's masked attention on the SAME bf16 values in fp32.  The only rounding the kernel adds is P
+    to bf16 before the second product (relative 2^-9 per weight, averaged over the open keys): 4e-3 of the output range.
+    Fully blocked rows (attend everywhere), a single open key, no mask at all, waves without a tile (N = 16), odd tile
+    counts per wave, more than 112 queries (two query chunks)."""
+    D = 32
+    g = torch.Generator().manual_seed(7 + N)
+    E = H * D
+    q = (torch.randn(B, Q, E, generator=g) * 0.5).to(torch.bfloat16)
+    k = torch.randn(B, N, E, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, N, E, generator=g).to(torch.bfloat16)
+    mask = torch.rand(B, Q, N, generator=g) < 0.7
+    mask[0, 0] = True  # fully blocked row -> attends everywhere
+    mask[0, 1] = True
+    mask[0, 1, N // 2] = False  # a single open key
+    if not use_mask:
+        mask = None
+    assert ops.masked_xattn_bf16_applies(dev(q), dev(k), dev(v), H)
+    row_open = None if mask is None else (~mask.all(-1)).to(torch.int32)
+    out = ops.masked_xattn(dev(q), dev(k), dev(v), None if mask is None else dev(mask.to(torch.uint8)),
+                           None if mask is None else dev(row_open), H)
+    assert out.dtype == torch.float32
+    sp = lambda t, n_: t.float().view(B, n_, H, D).permute(0, 2, 1, 3)
+    ref = O.masked_attention_core(sp(q, Q), sp(k, N), sp(v, N), mask if mask is not None else torch.zeros(B, Q, N, dtype=torch.bool))
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Q, E)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 4e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    if mask is not None:  # the single-open-key row is that key's v exactly (p = 1, l = 1)
+        torch.testing.assert_close(out[0, 1].cpu(), v[0, N // 2].float(), rtol=0, atol=1e-6)
+    # fp32 operands still take the fp32 kernel
+    assert not ops.masked_xattn_bf16_applies(dev(q.float()), dev(k.float()), dev(v.float()), H)
+
+
+@pytest.mark.parametrize("B,H,Q,N", [(2, 8, 100, 1024), (1, 8, 100, 4096), (1, 4, 37, 272), (1, 2, 200, 512)])
+def test_k2_bf16_autograd(ops, B, H, Q, N):
+    """Training under autocast: bf16 forward and backward kernels (Q = 200: two query chunks, the fp32 backward on fp32
+    copies) -- against the oracle's autograd in fp32 on the same bf16 values.  p, dS and the staged grad_out are rounded to
+    bf16 as matrix operands: 1e-2 of each gradient's range."""
+    D = 32
+    g = torch.Generator().manual_seed(3)
+    E = H * D
+    q = (torch.randn(B, Q, E, generator=g) * 0.5).to(torch.bfloat16)
+    k = torch.randn(B, N, E, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, N, E, generator=g).to(torch.bfloat16)
+    mask = torch.rand(B, Q, N, generator=g) < 0.7
+    mask[0, 0] = True
+    go = torch.randn(B, Q, E, generator=g)
+    qd, kd, vd = dev(q).requires_grad_(), dev(k).requires_grad_(), dev(v).requires_grad_()
+    out = ops.masked_xattn(qd, kd, vd, dev(mask.to(torch.uint8)), dev((~mask.all(-1)).to(torch.int32)), H)
+    out.backward(dev(go))
+    qr, kr, vr = q.float().requires_grad_(), k.float().requires_grad_(), v.float().requires_grad_()
+    sp = lambda t, n_: t.view(B, n_, H, D).permute(0, 2, 1, 3)
+    ref = O.masked_attention_core(sp(qr, Q), sp(kr, N), sp(vr, N), mask).permute(0, 2, 1, 3).reshape(B, Q, E)
+    ref.backward(go)
+    for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        assert got.dtype == torch.bfloat16
+        assert (got.float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (5000, 96, 256), (4097, 192, 256), (3000, 1024, 256), (3000, 256, 1024),
                                    (70, 288, 256), (63, 256, 256), (20000, 256, 256), (130, 8, 8), (777, 520, 264)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

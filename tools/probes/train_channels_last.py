@@ -9,11 +9,12 @@ from weed_instance_segmentation_amd.parallel import DataParallelEngine
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-for mode in ("nchw", "channels_last", "nchw", "channels_last"):
+for mode in ("nchw", "input_channels_last", "channels_last", "nchw", "input_channels_last", "channels_last"):
     model = bench.build_model(0).to(dev).train()
     x = torch.randn(B, 3, 1024, 1024, device=dev)
     if mode == "channels_last":
         model.model.pixel_level_module.encoder.to(memory_format=torch.channels_last)
+    if mode != "nchw":  # "input_channels_last": only the activations change format, the parameters (and the optimiser state) stay
         x = x.contiguous(memory_format=torch.channels_last)
     ml, cl = bench.synthetic_labels(B, 1024, 1024, seed=0, device=dev)
     eng = DataParallelEngine(model, lr=5e-5)

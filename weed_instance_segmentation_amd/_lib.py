@@ -56,6 +56,8 @@ SIGNATURES = {
     "wm2f_attn_mask_build": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_masked_xattn_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_masked_xattn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_masked_xattn_bf16_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm2f_masked_xattn_bf16_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_masked_xattn_bwd_workspace": (c_int64, [_I, _I, _I, _I, _I]),
     "wm2f_masked_xattn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_matcher_workspace": (c_int64, [_I, _I, _I, _I, _I]),

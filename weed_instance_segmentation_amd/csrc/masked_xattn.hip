@@ -642,6 +642,195 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_fwd_qsplit_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 form of the full-tile kernel (BASELINE configs 2-4 run under bf16 autocast, where the dependency's attention products
+// are bf16 matrix products with an fp32 softmax between them: baddbmm / softmax / bmm at TORCHF:6578-6600).
+// q, k, v arrive in bf16 AS THE in_proj LINEARS EMIT THEM -- (B, Q | N, heads * 32), no cast pass, half the K / V bytes;
+// both products run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation; S, the online softmax, (m, l) and O stay fp32 (the
+// dependency rounds S to bf16 before its softmax; this kernel does not); P is rounded to bf16 for the second product as the
+// dependency's bmm does.  Same split over keys, same (O, m, l) partials, same merge kernels as the fp32 form.
+//   S^T = K Q^T: A = K tile, lane (key n, group g) holds K[key][8 g .. 8 g + 7] -- ONE 16-byte load; its elements 0..3 feed MFMA
+//        step 0 and 4..7 step 1, i.e. the contraction index of (step s, group g, element i) is d = 8 g + 4 s + i, and Q^T is held
+//        in the same order.  C layout: column = query (lane & 15), rows = keys 4 g + r -- directly the B operand of
+//   O^T += V^T P^T: the A operand wants V TRANSPOSED (4 consecutive keys per lane at a fixed d).  V stays in its natural layout in
+//        HBM: lane (key n, group g) fetches V[key][8 g .. + 7] (16 bytes), the wave writes the 16 x 32 tile row-major into 1 KiB
+//        of its own LDS and reads it back with ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group, delivered column-major).
+template <int NQT>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bf16_fwd_full_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, float* __restrict__ ws, int Q, int N,
+    int heads, int n_splits, int tiles_per_split) {
+  constexpr int D = 32, DT = 2, QL = NQT * 16, RS = D + 4;
+  constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+  constexpr float kTau = 8.f;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+  __shared__ __attribute__((aligned(16))) float part[kXWaves][QL][RS];
+  __shared__ __attribute__((aligned(16))) uint16_t vtile[kXWaves][16 * D];  // a wave's V tile, [key][d] row-major
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x % n_splits, qc = blockIdx.x / n_splits;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qc * QL;
+  const int E = heads * D;
+  const float NEG_INF = -INFINITY;
+
+  s16x4 qf[NQT][2];
+  int qrow[NQT];
+  bool use_mask[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    int qi = q0 + 16 * j + n;
+    if (qi > Q - 1) qi = Q - 1;
+    qrow[j] = qi;
+    const s16x8 x = *reinterpret_cast<const s16x8*>(q + ((int64_t)b * Q + qi) * E + h * D + 8 * g);
+    qf[j][0] = __builtin_shufflevector(x, x, 0, 1, 2, 3);
+    qf[j][1] = __builtin_shufflevector(x, x, 4, 5, 6, 7);
+    use_mask[j] = mask != nullptr && (row_open == nullptr || row_open[(int64_t)b * Q + qi] != 0);
+  }
+
+  f32x4 o[DT][NQT];
+  float m[NQT], l[NQT];  // m: the reference maximum in LOG2 units (of s * log2 e)
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) {
+    m[j] = NEG_INF;
+    l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int n_tiles = N / 16;
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * N * E), 0, N * E * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * N * E), 0, N * E * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(mask != nullptr ? mask + (int64_t)b * Q * N : nullptr), 0, mask != nullptr ? Q * N : 0, 0x00020000);
+  const uint32_t kv_voff = (uint32_t)((n * E + h * D + 8 * g) * 2);  // K and V alike: lane (key0 + n, d = 8 g ..)
+  uint32_t m_voff[NQT];
+#pragma unroll
+  for (int j = 0; j < NQT; ++j) m_voff[j] = use_mask[j] ? (uint32_t)(qrow[j] * N + 4 * g) : 0x80000000u;
+  const int row_bytes = E * 2;
+
+  struct Frag {
+    s16x8 k, v;
+    uint32_t mb[NQT];
+  };
+  auto load_tile = [&](int tile, Frag& f) __attribute__((always_inline)) {
+    if (tile > n_tiles - 1) tile = n_tiles - 1;
+    const int soff = tile * 16 * row_bytes;
+    f.k = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kv_voff, soff, 0));
+    f.v = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, kv_voff, soff, 0));
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) f.mb[j] = __builtin_amdgcn_raw_buffer_load_b32(m_rsrc, m_voff[j], tile * 16, 0);
+  };
+  auto vmax = [](float x, float y) __attribute__((always_inline)) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  };
+  auto group_max = [&](float x) __attribute__((always_inline)) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = vmax(__builtin_bit_cast(float, (uint32_t)a[0]), __builtin_bit_cast(float, (uint32_t)a[1]));
+    const uint32_t w = __builtin_bit_cast(uint32_t, y);
+    const auto c = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return vmax(__builtin_bit_cast(float, (uint32_t)c[0]), __builtin_bit_cast(float, (uint32_t)c[1]));
+  };
+  // this wave's V tile in LDS: written row-major (lane (n, g): 16 bytes at row n, byte 16 g), read transposed
+  uint16_t* vt = &vtile[wave][0];
+  const int vt_wr = n * (D * 2) + g * 16;
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  const int vt_rd = (4 * g + tq) * (D * 2) + tp * 8;  // + 32 i for d tile i
+  auto compute = [&](const Frag& f, bool live) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<s16x8*>(reinterpret_cast<unsigned char*>(vt) + vt_wr) = f.v;
+    asm volatile("" ::: "memory");
+    const s16x4 k0 = __builtin_shufflevector(f.k, f.k, 0, 1, 2, 3), k1 = __builtin_shufflevector(f.k, f.k, 4, 5, 6, 7);
+    f32x4 s[NQT];
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      s[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k0, qf[j][0], s[j], 0, 0, 0);
+      s[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k1, qf[j][1], s[j], 0, 0, 0);
+    }
+    s16x4 va[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+      va[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(reinterpret_cast<unsigned char*>(vt) + vt_rd + 32 * i));
+    asm volatile("" ::: "memory");
+    float tmax[NQT];
+    bool grow = false;
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      uint32_t mb = f.mb[j];
+      asm volatile("" : "+v"(mb));
+      mb = live ? mb : 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[j][r] = ((mb >> (8 * r)) & 0xffu) != 0 ? NEG_INF : s[j][r] * kLog2e;
+      tmax[j] = group_max(fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])));
+      grow |= tmax[j] > m[j] + kTau;
+    }
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) {
+        const float m_new = fmaxf(m[j], tmax[j]);
+        const float m_s = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m[j] - m_s);
+        m[j] = m_new;
+        l[j] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[i][j] *= alpha;
+      }
+    }
+    s16x4 pb[NQT];
+#pragma unroll
+    for (int j = 0; j < NQT; ++j) {
+      const float m_safe = (m[j] == NEG_INF) ? 0.f : m[j];
+      float psum = 0.f;
+      bf16x4_t pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[j][r] - m_safe);
+        pk[r] = (__bf16)p;
+        psum += (float)pk[r];  // l sums what the second product really multiplies by: the rounded p
+      }
+      l[j] += psum;
+      pb[j] = __builtin_bit_cast(s16x4, pk);
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va[i], pb[j], o[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NQT; ++j) asm volatile("" : "+v"(o[i][j]));
+  };
+
+  Frag fa, fb;
+  int tile = split * tiles_per_split + wave;
+  load_tile(tile, fa);
+  while (tile < t_end) {
+    load_tile(tile + kXWaves, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fa, true);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(tile + 2 * kXWaves, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fb, tile + kXWaves < t_end);
+    __builtin_amdgcn_sched_barrier(0);
+    tile += 2 * kXWaves;
+  }
+
+  xattn_merge_waves<NQT, D>(part, o, m, l, kLn2, wave, g, n, ws, b, h, heads, Q, q0, n_splits, split);
+}
+
 // Merge the per-split partials: one thread per (b, h, q, float4 chunk of D).
 template <int D>
 __global__ __launch_bounds__(256) void masked_xattn_merge_kernel(const float* __restrict__ ws,
@@ -764,6 +953,46 @@ extern "C" int wm2f_masked_xattn_fwd(const void* q, const void* k, const void* v
   else
     hipLaunchKernelGGL((masked_xattn_merge_kernel<64>), mgrid, dim3(256), 0, st, (const float*)workspace,
                        (float*)out, (float*)lse, B, heads, Q, n_splits);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+/* bf16 operands (include/wm2f.h): q, k, v bf16, out / lse fp32.  Full-tile form only (N % 16 == 0, D = 32). */
+extern "C" int wm2f_masked_xattn_bf16_fwd(const void* q, const void* k, const void* v, const void* mask, const void* row_open,
+                                          void* out, void* lse, void* workspace, int B, int heads, int Q, int N, int D,
+                                          void* stream) {
+  const char* who = "wm2f_masked_xattn_bf16_fwd";
+  WM2F_REQUIRE(q && k && v && out && workspace, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && heads > 0 && Q > 0 && N > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads / B exceed the grid limits", who);
+  if (D != 32 || (N % 16) != 0 || (int64_t)N * heads * D * 2 >= (int64_t(1) << 31) || (int64_t)Q * N >= (int64_t(1) << 31) ||
+      (reinterpret_cast<uintptr_t>(mask) & 3) != 0 || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                                                        reinterpret_cast<uintptr_t>(v)) & 15) != 0) {
+    set_error("%s: needs head_dim 32, N %% 16 == 0, 16-byte aligned operands and 32-bit offsets (cast to fp32 and use "
+              "wm2f_masked_xattn_fwd)", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  const int n_splits = xattn_splits(B, heads, N);
+  const int n_tiles = N / 16;
+  const int tps = ceil_div(n_tiles, n_splits);
+  const int q_tiles = ceil_div(Q, 16);
+  const int q_chunks = ceil_div(q_tiles, 7);
+  const int nqt = ceil_div(q_tiles, q_chunks);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(kXWaves * kWave);
+#define WM2F_XB(NQTv)                                                                                                  \
+  hipLaunchKernelGGL((masked_xattn_bf16_fwd_full_kernel<NQTv>), dim3(n_splits* ceil_div(Q, NQTv * 16), heads, B), block, 0, \
+                     st, (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint8_t*)mask,              \
+                     (const int*)row_open, (float*)workspace, Q, N, heads, n_splits, tps)
+  if (nqt <= 1) WM2F_XB(1);
+  else if (nqt <= 2) WM2F_XB(2);
+  else if (nqt <= 4) WM2F_XB(4);
+  else WM2F_XB(7);
+#undef WM2F_XB
+  WM2F_CHECK_LAUNCH(who);
+  const int64_t total = (int64_t)B * heads * Q * (D / 4);
+  hipLaunchKernelGGL((masked_xattn_merge_kernel<32>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st,
+                     (const float*)workspace, (float*)out, (float*)lse, B, heads, Q, n_splits);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
@@ -1171,6 +1400,211 @@ __global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bwd_full_kernel(
   }
 }
 
+// bf16 form of the full-tile backward (bf16 autocast: q, k, v bf16 as saved by wm2f_masked_xattn_bf16_fwd; grad_out, lse, delta
+// fp32; grad_k / grad_v bf16, dQ partials fp32).  Same orientation and the same five products per (key tile, query tile) as the
+// fp32 kernel above, each as 2 v_mfma_f32_16x16x16_bf16 instead of 8 v_mfma_f32_16x16x4_f32; p and dS are computed in fp32 from
+// the fp32 accumulators and rounded to bf16 only as matrix operands.  Operand sources:
+//   S = Q K^T, dP = dO V^T      A = q / grad_out rows from the LDS staging (bf16), B = the lane's 16-byte K / V row piece
+//                               (contraction order d = 8 g + 4 s + i on both sides, as in the forward)
+//   dV^T += dO^T P, dK^T += Q^T dS   A = the staged rows read TRANSPOSED (ds_read_b64_tr_b16), B = p / dS as they stand
+//   dQ += dS K                  A = dS through a wave-private LDS tile (the one transpose the orientation leaves), B = the K
+//                               tile written to the wave's LDS image and read transposed
+template <int NQT>
+__global__ __launch_bounds__(kXWaves* kWave) void masked_xattn_bf16_bwd_full_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    const uint8_t* __restrict__ mask, const int* __restrict__ row_open, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ go, float* __restrict__ dq_ws,
+    uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int Q, int N, int heads, int n_splits, int tiles_per_split) {
+  constexpr int D = 32, DT = 2, QL = NQT * 16;
+  constexpr int PB = 80;  // bytes per staged row: 32 bf16 + 16 bytes of padding (16-byte aligned rows, spread over the banks)
+  constexpr int kStageBytes = 2 * QL * PB + QL * 12, kPartBytes = kXWaves * QL * D * 4;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kStageBytes > kPartBytes ? kStageBytes : kPartBytes)];
+  __shared__ __attribute__((aligned(16))) uint16_t ktile[kXWaves][16 * D];   // a wave's K tile, [key][d] row-major
+  __shared__ __attribute__((aligned(16))) uint16_t dst[kXWaves][16 * 20];    // a wave's dS tile, [q][key], 40-byte rows
+  unsigned char* qs = lds;                // [QL] rows of PB bytes
+  unsigned char* gs = lds + QL * PB;
+  float* ld2 = reinterpret_cast<float*>(lds + 2 * QL * PB);                  // [QL][2] = (lse, delta)
+  uint32_t* moff = reinterpret_cast<uint32_t*>(lds + 2 * QL * PB + QL * 8);  // [QL]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int E = heads * D;
+  const uint16_t* qb = q + (int64_t)b * Q * E + h * D;
+  const float* gob = go + (int64_t)b * Q * E + h * D;
+  for (int i = tid; i < QL * (D / 4); i += kXWaves * kWave) {  // 4 elements per thread: 8 bytes of q, 16 bytes of grad_out
+    const int r = i / (D / 4), c = i - r * (D / 4);
+    s16x4 x = {0, 0, 0, 0};
+    bf16x4_t y = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    if (r < Q) {
+      x = *reinterpret_cast<const s16x4*>(qb + (int64_t)r * E + 4 * c);
+      const float4 gv = *reinterpret_cast<const float4*>(gob + (int64_t)r * E + 4 * c);
+      y[0] = (__bf16)gv.x; y[1] = (__bf16)gv.y; y[2] = (__bf16)gv.z; y[3] = (__bf16)gv.w;
+    }
+    *reinterpret_cast<s16x4*>(qs + r * PB + 8 * c) = x;
+    *reinterpret_cast<bf16x4_t*>(gs + r * PB + 8 * c) = y;
+  }
+  for (int r = tid; r < QL; r += kXWaves * kWave) {
+    const bool ok = r < Q;
+    ld2[2 * r] = ok ? lse[((int64_t)b * heads + h) * Q + r] : INFINITY;
+    ld2[2 * r + 1] = ok ? delta[((int64_t)b * heads + h) * Q + r] : 0.f;
+    const bool use = mask != nullptr && ok && (row_open == nullptr || row_open[(int64_t)b * Q + r] != 0);
+    moff[r] = use ? (uint32_t)(r * N) : 0x80000000u;
+  }
+  __syncthreads();
+
+  const int n_tiles = N / 16;
+  int t_end = (split + 1) * tiles_per_split;
+  if (t_end > n_tiles) t_end = n_tiles;
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)b * N * E), 0, N * E * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)b * N * E), 0, N * E * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(mask != nullptr ? mask + (int64_t)b * Q * N : nullptr), 0, mask != nullptr ? Q * N : 0, 0x00020000);
+  const uint32_t kv_voff = (uint32_t)((n * E + h * D + 8 * g) * 2);  // lane (key0 + n, d = 8 g ..)
+  const int row_bytes = E * 2;
+  struct Frag {
+    s16x8 kf, vf;
+    uint32_t mb[4];
+  };
+  auto load_tile = [&](int tile, Frag& f) __attribute__((always_inline)) {
+    if (tile > n_tiles - 1) tile = n_tiles - 1;
+    const int soff = tile * 16 * row_bytes;
+    f.kf = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kv_voff, soff, 0));
+    f.vf = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, kv_voff, soff, 0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f.mb[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(m_rsrc, moff[4 * g + r] + (uint32_t)n, tile * 16, 0);
+  };
+
+  f32x4 dqa[NQT][DT];
+#pragma unroll
+  for (int jq = 0; jq < NQT; ++jq)
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dqa[jq][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint16_t* dvb = dv + (int64_t)b * N * E + h * D;
+  uint16_t* dkb = dk + (int64_t)b * N * E + h * D;
+  unsigned char* kt = reinterpret_cast<unsigned char*>(&ktile[wave][0]);
+  unsigned char* dt = reinterpret_cast<unsigned char*>(&dst[wave][0]);
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tr_row = 4 * g + tq;          // row of a transposed read's 4 x 16 block this lane addresses
+  const int kt_rd = tr_row * (D * 2) + tp * 8;  // + 32 i
+  auto pack4 = [](const f32x4& x) __attribute__((always_inline)) {
+    bf16x4_t r;
+    r[0] = (__bf16)x[0]; r[1] = (__bf16)x[1]; r[2] = (__bf16)x[2]; r[3] = (__bf16)x[3];
+    return __builtin_bit_cast(s16x4, r);
+  };
+
+  auto compute = [&](const Frag& f, int tile, bool live) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<s16x8*>(kt + n * (D * 2) + g * 16) = f.kf;  // the K tile, row-major, for the transposed read of dQ's B operand
+    asm volatile("" ::: "memory");
+    const s16x4 k0 = __builtin_shufflevector(f.kf, f.kf, 0, 1, 2, 3), k1 = __builtin_shufflevector(f.kf, f.kf, 4, 5, 6, 7);
+    const s16x4 v0 = __builtin_shufflevector(f.vf, f.vf, 0, 1, 2, 3), v1 = __builtin_shufflevector(f.vf, f.vf, 4, 5, 6, 7);
+    s16x4 kb[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) kb[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(kt + kt_rd + 32 * i));
+    f32x4 dvt[DT], dkt[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) dvt[i] = dkt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t mcur[4] = {f.mb[0], f.mb[1], f.mb[2], f.mb[3]};
+#pragma unroll
+    for (int jq = 0; jq < NQT; ++jq) {
+      uint32_t mnxt[4] = {0u, 0u, 0u, 0u};
+      if (jq + 1 < NQT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          mnxt[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(m_rsrc, moff[16 * (jq + 1) + 4 * g + r] + (uint32_t)n, tile * 16, 0);
+      }
+      // A operands of S and dP: lane (q = 16 jq + n, d = 8 g .. 8 g + 7)
+      const s16x8 qa = *reinterpret_cast<const s16x8*>(qs + (16 * jq + n) * PB + 16 * g);
+      const s16x8 ga = *reinterpret_cast<const s16x8*>(gs + (16 * jq + n) * PB + 16 * g);
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      sacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_shufflevector(qa, qa, 0, 1, 2, 3), k0, sacc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_shufflevector(ga, ga, 0, 1, 2, 3), v0, dp, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_shufflevector(qa, qa, 4, 5, 6, 7), k1, sacc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_shufflevector(ga, ga, 4, 5, 6, 7), v1, dp, 0, 0, 0);
+      f32x4 p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // rows of this lane: q = 16 jq + 4 g + r, column: key n
+        const float2 ld = *reinterpret_cast<const float2*>(ld2 + 2 * (16 * jq + 4 * g + r));
+        float pv = __expf(sacc[r] - ld.x);
+        pv = (mcur[r] != 0u || !live) ? 0.f : pv;
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - ld.y);
+      }
+      const s16x4 pb = pack4(p), dsb = pack4(ds);
+      // A operands of dV^T / dK^T: the staged rows transposed -- block rows q = 16 jq + 4 g .. + 3, columns d = 16 i ..
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const s16x4 got = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(gs + (16 * jq + tr_row) * PB + 32 * i + 8 * tp));
+        const s16x4 qt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(qs + (16 * jq + tr_row) * PB + 32 * i + 8 * tp));
+        dvt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(got, pb, dvt[i], 0, 0, 0);
+        dkt[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt, dsb, dkt[i], 0, 0, 0);
+      }
+      // dS to the query-on-lane layout through the wave's LDS tile: element (q = 4 g + r, key n) -> row q, then 4 keys per lane
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<short*>(dt + (4 * g + r) * 40 + 2 * n) = dsb[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const s16x4 dsa = *reinterpret_cast<const s16x4*>(dt + n * 40 + 8 * g);  // lane (q = n, keys 4 g .. 4 g + 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < DT; ++i) dqa[jq][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsa, kb[i], dqa[jq][i], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mcur[r] = mnxt[r];
+    }
+    if (live) {  // dV^T / dK^T tiles: column = key n, rows d = 16 i + 4 g + r -> 4 consecutive d of one key: 8 bytes of bf16
+      const int64_t ko = (int64_t)(tile * 16 + n) * E;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        *reinterpret_cast<s16x4*>(dvb + ko + 16 * i + 4 * g) = pack4(dvt[i]);
+        *reinterpret_cast<s16x4*>(dkb + ko + 16 * i + 4 * g) = pack4(dkt[i]);
+      }
+    }
+  };
+
+  Frag fa, fb;
+  int tile = split * tiles_per_split + wave;
+  load_tile(tile, fa);
+  while (tile < t_end) {
+    load_tile(tile + kXWaves, fb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fa, tile, true);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(tile + 2 * kXWaves, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(fb, tile + kXWaves, tile + kXWaves < t_end);
+    __builtin_amdgcn_sched_barrier(0);
+    tile += 2 * kXWaves;
+  }
+
+  // ---- merge dQ over the 4 waves through LDS (re-using the staging area): C layout of dqa is (column = d n, rows q = 4 g + r)
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(lds);  // [kXWaves][QL][D]
+#pragma unroll
+  for (int jq = 0; jq < NQT; ++jq)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(wave * QL + 16 * jq + 4 * g + r) * D + 16 * i + n] = dqa[jq][i][r];
+  __syncthreads();
+  for (int idx = tid; idx < QL * (D / 4); idx += kXWaves * kWave) {
+    const int ql = idx / (D / 4), c = idx - ql * (D / 4);
+    if (ql >= Q) continue;
+    float4 a = *reinterpret_cast<const float4*>(part + ql * D + 4 * c);
+#pragma unroll
+    for (int w = 1; w < kXWaves; ++w) {
+      const float4 x = *reinterpret_cast<const float4*>(part + (w * QL + ql) * D + 4 * c);
+      a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    }
+    *reinterpret_cast<float4*>(dq_ws + ((((int64_t)b * heads + h) * Q + ql) * n_splits + split) * D + 4 * c) = a;
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void xattn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq,
                                                               int B, int heads, int Q, int n_splits) {
@@ -1253,6 +1687,44 @@ extern "C" int wm2f_masked_xattn_bwd(const void* q, const void* k, const void* v
     WM2F_BD(64, 3)
   }
 #undef WM2F_BD
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
+/* bf16 operands (include/wm2f.h): q, k, v and grad_k / grad_v bf16; out, lse, grad_out, grad_q fp32.  Full-tile form only. */
+extern "C" int wm2f_masked_xattn_bf16_bwd(const void* q, const void* k, const void* v, const void* mask, const void* row_open,
+                                          const void* out, const void* lse, const void* grad_out, void* grad_q, void* grad_k,
+                                          void* grad_v, void* workspace, int B, int heads, int Q, int N, int D, void* stream) {
+  const char* who = "wm2f_masked_xattn_bf16_bwd";
+  WM2F_REQUIRE(q && k && v && out && lse && grad_out && grad_q && grad_k && grad_v && workspace, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && heads > 0 && Q > 0 && N > 0, "%s: non-positive size", who);
+  WM2F_REQUIRE(heads <= 65535 && B <= 65535, "%s: heads / B exceed the grid limits", who);
+  if (D != 32 || (N % 16) != 0 || Q > 112 || (int64_t)N * heads * D * 2 >= (int64_t(1) << 31) || (int64_t)Q * N >= (int64_t(1) << 31) ||
+      ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+        reinterpret_cast<uintptr_t>(grad_k) | reinterpret_cast<uintptr_t>(grad_v) | reinterpret_cast<uintptr_t>(grad_out)) & 15) != 0) {
+    set_error("%s: needs head_dim 32, N %% 16 == 0, Q <= 112, 16-byte aligned operands and 32-bit offsets (cast to fp32 and use "
+              "wm2f_masked_xattn_bwd)", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  const int n_splits = xattn_splits(B, heads, N, false);
+  const int tps = ceil_div(N / 16, n_splits);
+  hipStream_t st = (hipStream_t)stream;
+  float* dq_ws = (float*)workspace;
+  float* delta = dq_ws + (int64_t)B * heads * Q * n_splits * D;
+  const int64_t nrow = (int64_t)B * heads * Q;
+  hipLaunchKernelGGL((xattn_delta_kernel<32>), dim3((unsigned)ceil_div64(nrow, 256)), dim3(256), 0, st, (const float*)out,
+                     (const float*)grad_out, delta, B, heads, Q);
+#define WM2F_BB(NQTv)                                                                                                       \
+  hipLaunchKernelGGL((masked_xattn_bf16_bwd_full_kernel<NQTv>), dim3(n_splits, heads, B), dim3(kXWaves* kWave), 0, st,          \
+                     (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (const uint8_t*)mask, (const int*)row_open, \
+                     (const float*)lse, (const float*)delta, (const float*)grad_out, dq_ws, (uint16_t*)grad_k,              \
+                     (uint16_t*)grad_v, Q, N, heads, n_splits, tps)
+  if (ceil_div(Q, 16) <= 4) WM2F_BB(4);
+  else WM2F_BB(7);
+#undef WM2F_BB
+  WM2F_CHECK_LAUNCH(who);
+  hipLaunchKernelGGL((xattn_dq_reduce_kernel<32>), dim3((unsigned)ceil_div64(nrow * 8, 256)), dim3(256), 0, st, (const float*)dq_ws,
+                     (float*)grad_q, B, heads, Q, n_splits);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }

@@ -304,26 +304,52 @@ __global__ __launch_bounds__(kThreadsW) void token_wgrad_f32_kernel(WgradArgs a)
   }
 }
 
-// dW[n][k] = sum over splits (in split order) of the partial tiles; db likewise.  One thread per 4 consecutive k.
+// dW[n][k] = sum over splits of the partial tiles, db likewise -- in a FIXED order (deterministic): a workgroup owns 32
+// consecutive float4 of one dW row; its 8 thread rows each add every 8th split in ascending order, and the 8 sums are added
+// in thread-row order through LDS.  (One thread per output looping over 256 partials 256 KiB apart read at 0.7 TB/s.)
+constexpr int kRedGroups = 8;
 __global__ __launch_bounds__(256) void token_wgrad_reduce_kernel(const float* __restrict__ ws_w, const float* __restrict__ ws_b,
                                                                   float* __restrict__ dw, float* __restrict__ db, int N, int K,
                                                                   int cbk, int splits) {
-  const int kq = K / 4;
-  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (id < (long long)N * kq) {
-    const int n = (int)(id / kq), k = (int)(id - (long long)n * kq) * 4;
+  __shared__ f32x4 part[kRedGroups][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int kq = K / 4, segs = (kq + 31) / 32;  // 32-float4 segments per row
+  const int n = blockIdx.x / segs, k4 = (blockIdx.x - n * segs) * 32 + tx;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (n < N && k4 < kq) {
+    const int k = k4 * 4;
     const int cb = (n / kTile) * cbk + k / kTile;
     const float* p = ws_w + (size_t)cb * splits * (kTile * kTile) + (n % kTile) * kTile + (k % kTile);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < splits; ++i) s += *reinterpret_cast<const f32x4*>(p + (size_t)i * (kTile * kTile));
-    *reinterpret_cast<f32x4*>(dw + (size_t)n * K + k) = s;
+    // four loads in flight per thread (one at a time left the kernel latency-bound at 1.1 TB/s); the sum keeps a fixed order
+    int i = ty;
+    for (; i + 3 * kRedGroups < splits; i += 4 * kRedGroups) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)i * (kTile * kTile));
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + kRedGroups) * (kTile * kTile));
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + 2 * kRedGroups) * (kTile * kTile));
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + 3 * kRedGroups) * (kTile * kTile));
+      s += a0;
+      s += a1;
+      s += a2;
+      s += a3;
+    }
+    for (; i < splits; i += kRedGroups) s += *reinterpret_cast<const f32x4*>(p + (size_t)i * (kTile * kTile));
   }
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N && k4 < kq) {
+    f32x4 t = part[0][tx];
+#pragma unroll
+    for (int g = 1; g < kRedGroups; ++g) t += part[g][tx];
+    *reinterpret_cast<f32x4*>(dw + (size_t)n * K + k4 * 4) = t;
+  }
+  // bias: the first ceil(N / 256) workgroups, one thread per feature, splits in ascending order
+  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
   if (db && id < N) {
-    const int n = (int)id;
-    const float* p = ws_b + (size_t)(n / kTile) * splits * kTile + (n % kTile);
-    float s = 0.f;
-    for (int i = 0; i < splits; ++i) s += p[(size_t)i * kTile];
-    db[n] = s;
+    const int nb = (int)id;
+    const float* p = ws_b + (size_t)(nb / kTile) * splits * kTile + (nb % kTile);
+    float sb = 0.f;
+    for (int i = 0; i < splits; ++i) sb += p[(size_t)i * kTile];
+    db[nb] = sb;
   }
 }
 
@@ -392,9 +418,8 @@ extern "C" int wm2f_token_wgrad_bf16(const void* dy, const void* x, void* dw, vo
   }
   hipLaunchKernelGGL(token_wgrad_bf16_kernel, dim3(p.splits, p.cbn * p.cbk), dim3(kThreadsW), 4 * kImgBytes, (hipStream_t)stream, a);
   WM2F_CHECK_LAUNCH(who);
-  const long long work = (long long)N * (K / 4);
-  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.ws_w, a.ws_b,
-                     (float*)dw, (float*)db, N, K, p.cbk, p.splits);
+  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)(N * ((K / 4 + 31) / 32))), dim3(256), 0, (hipStream_t)stream, a.ws_w,
+                     a.ws_b, (float*)dw, (float*)db, N, K, p.cbk, p.splits);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
@@ -431,9 +456,8 @@ extern "C" int wm2f_token_wgrad_f32(const void* dy, const void* x, void* dw, voi
   }
   hipLaunchKernelGGL(token_wgrad_f32_kernel, dim3(p.splits, p.cbn * p.cbk), dim3(kThreadsW), 4 * kImgBytes32, (hipStream_t)stream, a);
   WM2F_CHECK_LAUNCH(who);
-  const long long work = (long long)N * (K / 4);
-  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.ws_w, a.ws_b,
-                     (float*)dw, (float*)db, N, K, p.cbk, p.splits);
+  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)(N * ((K / 4 + 31) / 32))), dim3(256), 0, (hipStream_t)stream, a.ws_w,
+                     a.ws_b, (float*)dw, (float*)db, N, K, p.cbk, p.splits);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }

@@ -498,9 +498,79 @@ class _MaskedXAttn(torch.autograd.Function):
         return gq, gk, gv, None, None, None
 
 
+def masked_xattn_bf16_applies(q, k, v, heads: int) -> bool:
+    """Shapes wm2f_masked_xattn_bf16_fwd is built for: bf16 q / k / v on a GPU, head_dim 32, whole 16-key tiles."""
+    if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.dim() == 3 and k.dim() == 3):
+        return False
+    E, N = q.shape[-1], k.shape[1]
+    return E == heads * 32 and N % 16 == 0 and N * E * 2 < (1 << 31) and q.shape[1] * N < (1 << 31)
+
+
+class _MaskedXAttnBf16(torch.autograd.Function):
+    """K2 on bf16 operands (what the in_proj Linears emit under bf16 autocast): forward on wm2f_masked_xattn_bf16_fwd, fp32
+    output; backward on wm2f_masked_xattn_bf16_bwd (up to 112 queries; beyond that the fp32 kernel on fp32 copies of the
+    saved operands); gradients return in bf16, the operands' dtype."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, row_open, heads):
+        q, k, v = _req(q, "q", torch.bfloat16), _req(k, "k", torch.bfloat16), _req(v, "v", torch.bfloat16)
+        B, Q, E = q.shape
+        N = k.shape[1]
+        D = E // heads
+        if k.shape != (B, N, E) or v.shape != (B, N, E) or D * heads != E:
+            raise ValueError(f"masked_xattn: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} heads {heads}")
+        if mask is not None:
+            mask = _req(mask, "mask", torch.uint8)
+            if mask.shape != (B, Q, N):
+                raise ValueError(f"masked_xattn: mask {tuple(mask.shape)} != {(B, Q, N)}")
+        if row_open is not None:
+            row_open = _req(row_open, "row_open", torch.int32)
+        out = torch.empty(B, Q, E, device=q.device, dtype=torch.float32)
+        lse = torch.empty(B, heads, Q, device=q.device, dtype=torch.float32)
+        lib = load()
+        ws = torch.empty(int(lib.wm2f_masked_xattn_workspace(B, heads, Q, N, D)), device=q.device, dtype=torch.uint8)
+        with torch.cuda.device(q.device):
+            check(_timed(f"masked_xattn_bf16_fwd_N{N}", q, lambda: lib.wm2f_masked_xattn_bf16_fwd(
+                _p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(ws), B, heads, Q, N, D, _stream(q))),
+                "wm2f_masked_xattn_bf16_fwd")
+        ctx.save_for_backward(q, k, v, mask, row_open, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, mask, row_open, out, lse = ctx.saved_tensors
+        grad_out = _req(grad_out.float(), "grad_out")
+        B, Q, E = q.shape
+        N, heads = k.shape[1], ctx.heads
+        D = E // heads
+        lib = load()
+        ws = torch.empty(int(lib.wm2f_masked_xattn_bwd_workspace(B, heads, Q, N, D)), device=q.device, dtype=torch.uint8)
+        with torch.cuda.device(q.device):
+            if Q <= 112:  # one query chunk: the bf16 backward kernel
+                gq = torch.empty(B, Q, E, device=q.device, dtype=torch.float32)
+                gk, gv = torch.empty_like(k), torch.empty_like(v)
+                check(_timed(f"masked_xattn_bf16_bwd_N{N}", q, lambda: lib.wm2f_masked_xattn_bf16_bwd(
+                    _p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(grad_out), _p(gq), _p(gk), _p(gv),
+                    _p(ws), B, heads, Q, N, D, _stream(q))), "wm2f_masked_xattn_bf16_bwd")
+                return gq.to(torch.bfloat16), gk, gv, None, None, None
+            # more queries (config 4: 200): the fp32 kernel on fp32 copies of the same bf16 values
+            q, k, v = q.float(), k.float(), v.float()
+            gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            check(_timed(f"masked_xattn_bwd_N{N}", q, lambda: lib.wm2f_masked_xattn_bwd(
+                _p(q), _p(k), _p(v), _p(mask), _p(row_open), _p(out), _p(lse), _p(grad_out), _p(gq), _p(gk), _p(gv),
+                _p(ws), B, heads, Q, N, D, WM2F_F32, _stream(q))), "wm2f_masked_xattn_bwd")
+        return gq.to(torch.bfloat16), gk.to(torch.bfloat16), gv.to(torch.bfloat16), None, None, None
+
+
 def masked_xattn(q, k, v, mask, row_open, heads: int) -> torch.Tensor:
     """K2 -- softmax(bias + q k^T) v with the shared byte mask (HF:1644-1650, TORCHF:6578-6600).
-    q (B,Q,E) pre-scaled by 1/sqrt(D); k, v (B,N,E); mask (B,Q,N) uint8 or None; row_open (B,Q) int32 or None."""
+    q (B,Q,E) pre-scaled by 1/sqrt(D); k, v (B,N,E); mask (B,Q,N) uint8 or None; row_open (B,Q) int32 or None.
+    bf16 q / k / v (bf16 autocast) with head_dim 32 and whole 16-key tiles run on the bf16 matrix cores and return fp32;
+    everything else computes in fp32."""
+    if masked_xattn_bf16_applies(q, k, v, heads):
+        with torch.autocast("cuda", enabled=False):
+            return _MaskedXAttnBf16.apply(q, k, v, mask, row_open, heads)
     return _MaskedXAttn.apply(q, k, v, mask, row_open, heads)
 
 
