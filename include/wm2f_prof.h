@@ -3,12 +3,22 @@
  * -DWM2F_PROFILING; `python -m weed_instance_segmentation_amd._build --prof`).  Used by tools/ only: never by the
  * product path, the tests' parity checks or bench.py.  It exports everything include/wm2f.h declares, plus:
  *
- *   - wm2f_msdeform_fwd_v accepts the timing ablations of K1, whose OUTPUTS ARE NOT VALID:
+ *   - wm2f_msdeform_fwd_v accepts, beside the production variants 0 / 1 / 2 / 4:
+ *     superseded kernels and measured negatives (valid outputs; the baselines DESIGN.md's numbers are quoted against)
+ *       3                       phased quad kernel (superseded by the streaming form)
+ *       5 / 6 / 7               streaming kernel with per-window flags instead of barriers / tiles in 2-wide strips / the
+ *                               round-1 loader schedule
+ *       8                       streaming kernel in its half-head form (two 77-KiB workgroups per CU)
+ *       62                      LDS-window kernel in slab-major work order
+ *     timing ablations, whose OUTPUTS ARE NOT VALID
  *       12 / 22 / 32 / 42 / 52  LDS-window kernel: staging only, gather only, no operand loads, no LDS reads, neither
  *       13 / 23 / 43            phased quad kernel: staging only, gather only, no LDS reads
  *       44                      streaming quad kernel (full-head form) without LDS reads
+ *     stamped builds (valid outputs)
  *       73 / 74 / 84            phased / full-head streaming / half-head streaming kernel with in-kernel time stamps
- *                               (valid outputs)
+ *   - wm2f_msdeform_fused_lanes_fwd reads WM2F_K1_MODE on every launch: 200 strip order, 300 round-1 loader schedule, 500
+ *     Z-order, 600 / 700 static wave priority, 800 slab order, 801 / 802 / 803 slab order with non-temporal operand loads /
+ *     output stores / both, 807 slab order stamped (tools/k1_slab_inmodel.py, tools/k1_stamps.py)
  *   - K2 / K3 read their experiment knobs from the environment on every launch
  *       WM2F_K2_QTILES, WM2F_K2_WG_TARGET, WM2F_K2_FULL, WM2F_K2_QSPLIT, WM2F_K3_DBG   (tools/kbench.py)
  *   - the stamp buffer below: a __device__ global, i.e. the global mutable state the production library forbids.

@@ -4,7 +4,8 @@
          wm2f_token_linear_fwd(out_group = 36);  hv = hm + the value tensor head-major too, (heads, B, S, 32)
   mode   0 = what the product runs for these rows (tm: heads innermost, 4 tiles x 8 heads resident per XCD; hm / hv: slab order);
          800 = SLAB order (heads outermost: the XCD's 32 workgroups walk one (image, head) slab together); 801 / 802 / 803 = slab
-         order + non-temporal operand loads / output stores / both; 811 = slab order + output rows stored from inside the fine gather
+         order + non-temporal operand loads / output stores / both; 814 / 815 / 816 = timing ablations of the slab-order kernel (no LDS reads / no window DMA / no operand loads and stores):
+         OUTPUTS NOT VALID, the model's later layers see garbage -- only the K1 launch time means anything
 
 Only in the model is the launch fed from HBM (kbench launches find their operands in L2 / Infinity Cache).
 Usage: python tools/k1_slab_inmodel.py [--cases tm:0,hm:0,hm:800,...] [--iters 10] [--rounds 2]
@@ -24,7 +25,7 @@ _lib.use_profiling_library()
 import bench  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--cases", default="tm:0,hm:0,hm:802,hm:811")
+ap.add_argument("--cases", default="tm:0,hm:0,hm:802")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--batch", type=int, default=8)
@@ -52,7 +53,7 @@ def kernel_check(modes):
     assert all(res.values()), res
 
 
-kernel_check(sorted({int(c.split(":")[1]) for c in args.cases.split(",")} - {0}))
+kernel_check(sorted(m for m in {int(c.split(":")[1]) for c in args.cases.split(",")} - {0} if m < 810))  # 814-816: timing ablations, outputs not valid
 model = bench.build_model().to(dev).eval()
 x = torch.randn(args.batch, 3, 1024, 1024, device=dev)
 ref_out = None

@@ -1021,9 +1021,9 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     constexpr int kFA = 26, kFB = LWin<2>::n - kFA;
     TileWalk walk = walk_init<kOrder>(first, sg, heads * kSplit);
     LoaderTile lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
-    loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
+    if (MODE != 5) loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
     __builtin_amdgcn_sched_barrier(0);
-    loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
+    if (MODE != 5) loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
     if (SYNC == 1) {
       for (int k = 0; k < n_my; ++k) {
         wait_vm<LWin<1>::n>();  // coarse(k) landed
@@ -1031,17 +1031,17 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         wait_vm<0>();           // mid(k) landed
         publish(&ctrl[kCtrlReady + 1 * 2 + ld], k + 1, lane);
         poll_ge(&ctrl[kCtrlDone + 2], kGW * k);  // every gather wave is done with fine(k - 1)
-        loader_issue<2, 0, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
+        if (MODE != 5) loader_issue<2, 0, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
         wait_vm<0>();
         publish(&ctrl[kCtrlReady + 2 * 2 + ld], k + 1, lane);
         if (k + 1 < n_my) {
           walk_step<kOrder>(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           poll_ge(&ctrl[kCtrlDone + 0], kGW * (k + 1));
-          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
+          if (MODE != 5) loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
           __builtin_amdgcn_sched_barrier(0);
           poll_ge(&ctrl[kCtrlDone + 1], kGW * (k + 1));
-          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
+          if (MODE != 5) loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
         }
       }
       return;
@@ -1052,12 +1052,12 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       WM2F_SSTAMP(10, kLoaderWave0);
       wg_barrier();           // Bc(k): gather waves are done with fine(k-1)
       WM2F_SSTAMP(11, kLoaderWave0);
-      loader_issue<2, 0, kFA, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
+      if (MODE != 5) loader_issue<2, 0, kFA, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
       WM2F_SSTAMP(12, kLoaderWave0);
       wait_vm<kFA>();  // mid(k) landed
       wg_barrier();    // Bm(k): gather waves are done with coarse(k)
       WM2F_SSTAMP(13, kLoaderWave0);
-      loader_issue<2, kFA, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
+      if (MODE != 5) loader_issue<2, kFA, LWin<2>::n, CH>((lds4_t)win2, r2, lt.slab[2], ld, lt.tile_off[2], lt.x_border, lt.wx0[2], g.W[2], pix_lane);
       if (kSched1) {
         // Per-wave stamps (profiles/r02_k1_stream_stamps_*.json): with coarse(k + 1) requested here the loaders were the
         // last to reach Bf(k) in every workgroup, 1.5k cycles behind the gather waves.  The coarse window is not needed
@@ -1070,9 +1070,9 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
           walk_step<kOrder>(walk, sg, heads * kSplit);
           lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
           __builtin_amdgcn_sched_barrier(0);
-          loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
+          if (MODE != 5) loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
           __builtin_amdgcn_sched_barrier(0);
-          loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
+          if (MODE != 5) loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
         }
         continue;
       }
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         walk_step<kOrder>(walk, sg, heads * kSplit);
         lt = loader_tile(value, sg, walk_tile(walk, sg, kSplit), S, heads, kPB);
         __builtin_amdgcn_sched_barrier(0);
-        loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
+        if (MODE != 5) loader_issue<0, 0, LWin<0>::n, CH>((lds4_t)win0, r0, lt.slab[0], ld, lt.tile_off[0], lt.x_border, lt.wx0[0], g.W[0], pix_lane, lane_part, row_bytes);
         wait_vm<LWin<0>::n>();  // fine(k) landed
       } else {
         wait_vm<0>();
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       WM2F_SSTAMP(15, kLoaderWave0);
       if (more) {
         __builtin_amdgcn_s_sleep(24);  // ~1.5k cycles: leave the memory path to the gather waves' operand loads
-        loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
+        if (MODE != 5) loader_issue<1, 0, LWin<1>::n, CH>((lds4_t)win1, r1, lt.slab[1], ld, lt.tile_off[1], lt.x_border, lt.wx0[1], g.W[1], pix_lane, lane_part, row_bytes);
       }
     }
     (void)kFB;
@@ -1236,14 +1236,17 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         // slab when the rows are stored head-major)
         const int rec = (int)__umul24((unsigned)q, (unsigned)a_row) + o.h * b_row;
         const int off = rec + (kAligned ? j * 16 : j * 36);
-        const f32x4q A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, kOpAux));
-        const f32x4q Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + (kAligned ? 64 : 16), 0, kOpAux));
+        f32x4q A = {0.f, 0.f, 0.f, 0.f}, Bq = {0.f, 0.f, 0.f, 0.f};
+        if (MODE != 6) {  // (MODE 6, profiling build: timing ablation without the gather waves' loads and stores)
+          A = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, kOpAux));
+          Bq = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + (kAligned ? 64 : 16), 0, kOpAux));
+        }
         o.lc[t2][0] = make_float2(A.x, A.y);
         o.lc[t2][1] = make_float2(A.z, A.w);
         o.lc[t2][2] = make_float2(Bq.x, Bq.y);
         o.wt[t2][0] = Bq.z;
         o.wt[t2][1] = Bq.w;
-        o.wt[t2][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, kAligned ? rec + 128 + j * 4 : off + 32, 0, kOpAux));
+        o.wt[t2][2] = MODE == 6 ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, kAligned ? rec + 128 + j * 4 : off + 32, 0, kOpAux));
       } else {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -1406,6 +1409,10 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         }
       }
       const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4) + cur.hh * 64) : kOobOffset;
+      if (MODE == 6) {  // keep the sums alive without a store
+        asm volatile("" ::"v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y), "v"(r2.z), "v"(r2.w));
+        continue;
+      }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, kStAux);
       if (CH == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r2), out_rs, (int)(o_off + off2), 0, kStAux);
     }
@@ -1562,7 +1569,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.step_h = sg.wg_per_xcd % (heads * split);
   sg.step_tx = sg.step_ty = 0;
   // slab order (lanes bit 2; profiling build: modes 800-803, bit 0 / 1 = non-temporal operand loads / output stores)
-  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 807));
+  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 816));
   if (slab) {
     const int n_tiles = g.tiles_x * g.tiles_y;
     sg.step_h = sg.wg_per_xcd / n_tiles;
@@ -1594,6 +1601,10 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
     if (mode == 802 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 512>;
     if (mode == 803 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 256 + 512>;
     if (mode == 807 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 9 + 128>;
+    // timing ablations of the slab-order kernel (OUTPUTS NOT VALID): 814 no LDS reads, 815 no window DMA, 816 no operand loads / stores
+    if (mode == 814 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true, 9 + 128>;
+    if (mode == 815 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 5, 0, 8, true, 9 + 128>;
+    if (mode == 816 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 6, 0, 8, true, 9 + 128>;
 #endif
   }
   int threads = SCfg<8>::THREADS;
