@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
 # HBM bytes per K1 launch from the PMC counters of a separate rocprofv3 run over this same command (tools/pmc_bench.sh;
 # counters cannot be collected inside the driver's own run): the newest committed measurement
-K1_TRAFFIC_PROFILE = "r02_pmc_k1_traffic.json"
+K1_TRAFFIC_PROFILE = "r03_pmc_k1_traffic.json"
 
 
 def build_model(seed=0, num_labels=3, num_queries=100):
@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--train-leg", type=int, default=1, help="1: after the default run also time a short configs[2] train leg (0 = skip)")
     ap.add_argument("--amp", choices=["off", "bf16"], default="off",
-                    help="bf16: run the step under torch.autocast(bfloat16) (BASELINE configs 3-5); the wm2f kernels keep fp32 arithmetic")
+                    help="bf16: run the step under torch.autocast(bfloat16) (BASELINE configs 2-4)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,7 +210,7 @@ def main():
             "metric": f"images/sec at {S}x{S} bs={B} per GPU (Mask2Former R50, 100 queries, {prec} {what.split(' (')[0]})",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if a.amp == "off" else "bf16 autocast (stock ops bf16, wm2f kernels f32)", "data": "synthetic (randn pixels, random-init weights seed 0)",
+            "vs_baseline": None, "dtype": "f32" if a.amp == "off" else "bf16 autocast (stock ops, K2, K3 and the token weight gradients on bf16 operands; K1, matcher, point sampler compute fp32)", "data": "synthetic (randn pixels, random-init weights seed 0)",
             "config": {"workload": f"{which}: synthetic {S}x{S} 3-class, ResNet-50 Mask2Former, 100 queries, {prec} {what}, "
                                    f"bs={B} per GPU", "global_batch": world * B, "image_size": S,
                        "parallelism": f"dp{world}", "mode": a.mode, "amp": a.amp},

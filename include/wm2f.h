@@ -278,6 +278,26 @@ int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y
 int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,
                        const void* pos, void* out, void* out_plus_pos, int64_t rows, int C,
                        int64_t pos_rows, float eps, void* stream);
+/* wm2f_add_layernorm_train_fwd / _bwd: the same residual add + LayerNorm for the TRAIN step (HF:1076-1078, :1086-1088, and the
+ *                     next layer's `hidden + pos`, HF:972), C = 256, with the tensors its consumers read written in the same pass:
+ *                       y (rows, 256) fp32 = LayerNorm(x + residual) * gamma + beta;   x fp32 or bf16 (x_dtype), residual fp32 or NULL
+ *                       y_bf16      NULL, or y rounded to bf16 (the next Linear's operand under bf16 autocast)
+ *                       y_plus_pos  NULL, or y + pos[row % pos_rows] in yp_dtype (fp32 / bf16)
+ *                       stats (rows, 2) fp32 = (mean, rstd) for the backward.
+ *                     Backward: the gradients of the three outputs (any of them NULL) are summed in registers;
+ *                       grad_sum (rows, 256) fp32 = d loss / d (x + residual) (NULL: not written), grad_x the same in x's dtype
+ *                       (NULL: not written), grad_gamma / grad_beta (256) fp32 -- per-workgroup partial sums over fixed row
+ *                       ranges in `workspace` (wm2f_add_layernorm_train_workspace(rows) bytes), added in workgroup order:
+ *                       deterministic.  Replaces torch's two LayerNorm-backward kernels, the gradient-accumulation adds and the
+ *                       casts around them; every operand byte moves once (HBM-bound). */
+int64_t wm2f_add_layernorm_train_workspace(int64_t rows);
+int wm2f_add_layernorm_train_fwd(const void* x, int x_dtype, const void* residual, const void* gamma, const void* beta,
+                                 const void* pos, void* y, void* y_bf16, void* y_plus_pos, int yp_dtype, void* stats,
+                                 int64_t rows, int C, int64_t pos_rows, float eps, void* stream);
+int wm2f_add_layernorm_train_bwd(const void* x, int x_dtype, const void* residual, const void* gamma, const void* stats,
+                                 const void* grad_y, const void* grad_y_bf16, const void* grad_y_plus_pos, int gyp_dtype,
+                                 void* grad_sum, void* grad_x, void* grad_gamma, void* grad_beta, void* workspace,
+                                 int64_t rows, int C, void* stream);
 /* wm2f_token_linear_fwd: out (M, N) = epilogue(x (M, K) . W (N, K)^T + bias[N]) on the fp32 matrix cores, for the narrow Linears
  *                        of the pixel decoder's encoder layers (HF:978 value_proj, :983-991 sampling_offsets | attention_weights
  *                        merged, :1012 output_proj, :1086 fc2).  N = 256 or 288, K % 64 == 0, all fp32 row-major (W as

@@ -849,6 +849,81 @@ def test_k2_bf16_autograd(ops, B, H, Q, N):
         assert (got.float().cpu() - want).abs().max().item() <= 1e-2 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("rows,pos_rows,x_bf16,want_lp,use_res", [(4096, 1024, True, True, True), (1000, 500, True, True, True),
+                                                                 (777, 777, False, False, True), (130, 0, True, True, True),
+                                                                 (3, 0, False, False, False), (5000, 2500, False, False, True)])
+def test_add_layernorm_train(ops, rows, pos_rows, x_bf16, want_lp, use_res):
+    """ops.add_layernorm_train (residual add + LayerNorm of the encoder layers in training, with the bf16 copy and y + pos from
+    the same pass and ONE backward pass) against the same chain of stock torch ops with autograd, in fp64 on the CPU: all three
+    outputs, and the gradients of x, residual, gamma, beta and pos when every output carries a gradient (and when only some do).
+    Ragged row counts (not a multiple of the 128-row workgroup range), no residual, no pos; two backward runs give identical
+    bits (gamma / beta partials are added in workgroup order)."""
+    g = torch.Generator().manual_seed(rows)
+    C = 256
+    x = torch.randn(rows, C, generator=g) * 2
+    if x_bf16:
+        x = x.to(torch.bfloat16)
+    res = torch.randn(rows, C, generator=g) if use_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    pos = torch.randn(pos_rows, C, generator=g) if pos_rows else None
+    gy, glp = torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g).to(torch.bfloat16)
+    gyp = torch.randn(rows, C, generator=g)
+    if x_bf16:
+        gyp = gyp.to(torch.bfloat16)
+
+    def run(with_gy=True):
+        xd = dev(x).requires_grad_()
+        rd = dev(res).requires_grad_() if use_res else None
+        gd, bd = dev(gamma).requires_grad_(), dev(beta).requires_grad_()
+        pd = dev(pos).requires_grad_() if pos is not None else None
+        y, ylp, yp = ops.add_layernorm_train(xd, rd, gd, bd, 1e-5, pos=pd, want_bf16=want_lp, pos_bf16=x_bf16)
+        outs, gs = [], []
+        if with_gy:
+            outs.append(y); gs.append(dev(gy))
+        if want_lp:
+            outs.append(ylp); gs.append(dev(glp))
+        if pos is not None:
+            outs.append(yp); gs.append(dev(gyp))
+        torch.autograd.backward(outs, gs)
+        return (y, ylp, yp), (xd.grad, None if rd is None else rd.grad, gd.grad, bd.grad, None if pd is None else pd.grad)
+
+    (y, ylp, yp), grads = run()
+    # reference in fp64
+    xr = x.double().requires_grad_()
+    rr = res.double().requires_grad_() if use_res else None
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    pr = pos.double().requires_grad_() if pos is not None else None
+    yr = torch.nn.functional.layer_norm(xr + rr if use_res else xr, (C,), gr, br, 1e-5)
+    loss = (yr * gy.double()).sum()
+    if want_lp:
+        loss = loss + (yr * glp.double()).sum()
+    if pos is not None:
+        ypr = yr + pr.repeat(rows // pos_rows, 1)
+        loss = loss + (ypr * gyp.double()).sum()
+    loss.backward()
+    torch.testing.assert_close(y.cpu().double(), yr.detach(), rtol=1e-5, atol=2e-5)
+    if want_lp:
+        assert torch.equal(ylp, y.to(torch.bfloat16))
+    if pos is not None:
+        torch.testing.assert_close(yp.float().cpu().double(), ypr.detach(), rtol=1e-2 if x_bf16 else 1e-5, atol=3e-2 if x_bf16 else 2e-5)
+    gx, gres, gg, gb, gp = grads
+    tol = dict(rtol=2e-2, atol=3e-2) if x_bf16 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gx.float().cpu().double(), xr.grad, **tol)
+    if use_res:
+        torch.testing.assert_close(gres.cpu().double(), rr.grad, rtol=1e-4, atol=1e-4)
+    scale = float(gr.grad.abs().max())
+    assert (gg.cpu().double() - gr.grad).abs().max().item() <= 2e-5 * scale * math.sqrt(rows)
+    assert (gb.cpu().double() - br.grad).abs().max().item() <= 2e-5 * float(br.grad.abs().max()) * math.sqrt(rows) + 1e-4
+    if pos is not None:
+        torch.testing.assert_close(gp.cpu().double(), pr.grad, rtol=1e-4, atol=1e-3)
+    _, grads2 = run()
+    for a_, b_ in zip(grads, grads2):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
+    if want_lp or pos is not None:  # a subset of the outputs carries a gradient (the last layer's y feeds no residual stream ...)
+        _, g3 = run(with_gy=False)
+        assert all(torch.isfinite(t).all() for t in g3 if t is not None)
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (5000, 96, 256), (4097, 192, 256), (3000, 1024, 256), (3000, 256, 1024),
                                    (70, 288, 256), (63, 256, 256), (20000, 256, 256), (130, 8, 8), (777, 520, 264)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -10,7 +10,7 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-images 0 > $O/p$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-images 0 --train-leg 0 > $O/p$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json, re

@@ -1569,7 +1569,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.step_h = sg.wg_per_xcd % (heads * split);
   sg.step_tx = sg.step_ty = 0;
   // slab order (lanes bit 2; profiling build: modes 800-803, bit 0 / 1 = non-temporal operand loads / output stores)
-  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 816));
+  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 817));
   if (slab) {
     const int n_tiles = g.tiles_x * g.tiles_y;
     sg.step_h = sg.wg_per_xcd / n_tiles;
@@ -1602,6 +1602,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
     if (mode == 803 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 256 + 512>;
     if (mode == 807 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 9 + 128>;
     // timing ablations of the slab-order kernel (OUTPUTS NOT VALID): 814 no LDS reads, 815 no window DMA, 816 no operand loads / stores
+    if (mode == 817 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 2>;      // slab + round-1 loader schedule
     if (mode == 814 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true, 9 + 128>;
     if (mode == 815 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 5, 0, 8, true, 9 + 128>;
     if (mode == 816 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 6, 0, 8, true, 9 + 128>;

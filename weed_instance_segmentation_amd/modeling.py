@@ -125,8 +125,9 @@ class MSDeformAttn(nn.Module):
             return self._cat["w_lanes"], self._cat["b_lanes"]
         return self._cat["w"], self._cat["b"]
 
-    def forward(self, hidden, pos, ref, level_hw, hp=None):
-        """hidden (B,S,C); pos (S,C) shared by the batch; ref (S,L,2); hp = hidden + pos if already known."""
+    def forward(self, hidden, pos, ref, level_hw, hp=None, hidden_lp=None):
+        """hidden (B,S,C); pos (S,C) shared by the batch; ref (S,L,2); hp = hidden + pos if already known (training: possibly in
+        bf16, as the fused LayerNorm of the previous layer wrote it); hidden_lp = hidden in bf16 if already known."""
         B, S, C = hidden.shape
         H, L, P = self.n_heads, self.n_levels, self.n_points
         if hp is None:
@@ -134,7 +135,7 @@ class MSDeformAttn(nn.Module):
         if torch.is_grad_enabled() and (hidden.requires_grad or self.value_proj.weight.requires_grad):
             # (ops.linear_tokens = F.linear; under bf16 autocast its weight gradient runs on wm2f_token_wgrad_bf16)
             lin = ops.linear_tokens
-            value = lin(hidden, self.value_proj.weight, self.value_proj.bias).view(B, S, H, C // H)
+            value = lin(hidden if hidden_lp is None else hidden_lp, self.value_proj.weight, self.value_proj.bias).view(B, S, H, C // H)
             # sampling_offsets and attention_weights as ONE projection of hp (one cast, one GEMM, one weight-gradient pass
             # instead of two); the concatenation is tracked by autograd, so each Linear's parameters get their rows of dW
             so, aw_ = self.sampling_offsets, self.attention_weights
@@ -181,8 +182,12 @@ class PixelDecoderEncoderLayer(nn.Module):
         self.fc2 = nn.Linear(config.encoder_feedforward_dim, d)
         self.final_layer_norm = nn.LayerNorm(d)
 
-    def forward(self, hidden, pos, ref, level_hw, hp=None):
-        """Returns (hidden, hidden + pos or None).  pos is (S, C), shared by the batch."""
+    def forward(self, hidden, pos, ref, level_hw, hp=None, emit_next=True):
+        """Returns (hidden, next) where next = hidden + pos (inference), (hidden + pos, hidden in bf16 or None) (training, fused
+        LayerNorm route) or None.  pos is (S, C), shared by the batch; emit_next=False for the last layer."""
+        hidden_lp = None
+        if isinstance(hp, tuple):
+            hp, hidden_lp = hp
         if (not torch.is_grad_enabled() and self.dropout == 0.0 and hidden.shape[-1] == 256
                 and hidden.dtype == torch.float32 and not torch.is_autocast_enabled("cuda")):
             # inference: residual + LayerNorm fused (and the next layer's hidden + pos with the second one);
@@ -194,15 +199,32 @@ class PixelDecoderEncoderLayer(nn.Module):
             f = torch._addmm_activation(self.fc1.bias, hidden.reshape(B_ * S_, C_), self.fc1.weight.t(), use_gelu=False)
             f = self.fc2(f).view(B_, S_, C_)
             return ops.add_layernorm(f, hidden, ln2.weight, ln2.bias, ln2.eps, pos=pos)
-        a = F.dropout(self.self_attn(hidden, pos, ref, level_hw, hp), self.dropout, self.training)
-        hidden = self.self_attn_layer_norm(hidden + a)
-        f = F.dropout(F.relu(ops.linear_tokens(hidden, self.fc1.weight, self.fc1.bias)), self.dropout, self.training)
-        f = F.dropout(ops.linear_tokens(f, self.fc2.weight, self.fc2.bias), self.dropout, self.training)
-        hidden = self.final_layer_norm(hidden + f)
+        amp = torch.is_autocast_enabled("cuda")
+        bf16 = amp and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if (torch.is_grad_enabled() and self.dropout == 0.0 and hidden.is_cuda and hidden.shape[-1] == 256
+                and hidden.dtype == torch.float32 and (bf16 or not amp)):
+            # training: residual add + LayerNorm as ONE pass that also writes what the next Linears read (the bf16 copy under
+            # autocast, and the next layer's hidden + pos), with ONE backward pass (ops.add_layernorm_train)
+            ln1, ln2 = self.self_attn_layer_norm, self.final_layer_norm
+            a = self.self_attn(hidden, pos, ref, level_hw, hp, hidden_lp)
+            hidden, h_lp, _ = ops.add_layernorm_train(a, hidden, ln1.weight, ln1.bias, ln1.eps, want_bf16=bf16)
+            f = F.relu(ops.linear_tokens(hidden if h_lp is None else h_lp, self.fc1.weight, self.fc1.bias))
+            f = ops.linear_tokens(f, self.fc2.weight, self.fc2.bias)
+            hidden, h_lp, hp_next = ops.add_layernorm_train(f, hidden, ln2.weight, ln2.bias, ln2.eps, pos=pos if emit_next else None,
+                                                             want_bf16=bf16 and emit_next, pos_bf16=bf16)
+            nxt = (hp_next, h_lp) if emit_next else None
+        else:
+            a = F.dropout(self.self_attn(hidden, pos, ref, level_hw, hp, hidden_lp), self.dropout, self.training)
+            hidden = self.self_attn_layer_norm(hidden + a)
+            f = F.dropout(F.relu(ops.linear_tokens(hidden, self.fc1.weight, self.fc1.bias)), self.dropout, self.training)
+            f = F.dropout(ops.linear_tokens(f, self.fc2.weight, self.fc2.bias), self.dropout, self.training)
+            hidden = self.final_layer_norm(hidden + f)
+            nxt = None
         if self.training and not torch.isfinite(hidden).all():  # HF:1090-1093
             cv = torch.finfo(hidden.dtype).max - 1000
             hidden = torch.clamp(hidden, min=-cv, max=cv)
-        return hidden, None
+            nxt = None  # (the by-products were written from the unclamped values)
+        return hidden, nxt
 
 
 class PixelDecoderEncoderOnly(nn.Module):
@@ -224,8 +246,8 @@ class PixelDecoderEncoderOnly(nn.Module):
     def forward(self, hidden, pos, level_hw):
         ref = self.reference_points(level_hw, hidden.device, hidden.dtype)
         hp = None
-        for layer in self.layers:
-            hidden, hp = layer(hidden, pos, ref, level_hw, hp)
+        for i, layer in enumerate(self.layers):
+            hidden, hp = layer(hidden, pos, ref, level_hw, hp, emit_next=i + 1 < len(self.layers))
         return hidden
 
 

@@ -711,6 +711,93 @@ def add_layernorm(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None
     return (out, out_pos) if pos is not None else out
 
 
+class _AddLayerNormTrain(torch.autograd.Function):
+    """LayerNorm(x + res) with its consumers' tensors from the same pass, and ONE backward pass (include/wm2f.h,
+    wm2f_add_layernorm_train_*).  Returns (y fp32, y in bf16 or None, y + pos in bf16 / fp32 or None)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, pos, want_lp, yp_bf16):
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"add_layernorm_train: x is {x.dtype}")
+        x = _req(x, "x", x.dtype)
+        gamma, beta = _req(gamma, "gamma"), _req(beta, "beta")
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if res is not None:
+            res = _req(res, "residual")
+            if res.shape != x.shape:
+                raise ValueError("add_layernorm_train: residual shape")
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        y_lp = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if want_lp else None
+        yp, pos_rows = None, 0
+        if pos is not None:
+            pos = _req(pos, "pos")
+            pos_rows = pos.numel() // C
+            if rows % pos_rows:
+                raise ValueError("add_layernorm_train: pos rows do not divide the token count")
+            yp = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if yp_bf16 else torch.float32)
+        stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+        xd = _lib.WM2F_BF16 if x.dtype == torch.bfloat16 else WM2F_F32
+        with torch.cuda.device(x.device):
+            check(_timed("add_layernorm_train_fwd", x, lambda: load().wm2f_add_layernorm_train_fwd(
+                _p(x), xd, _p(res), _p(gamma), _p(beta), _p(pos), _p(y), _p(y_lp), _p(yp), _lib.WM2F_BF16 if yp_bf16 else WM2F_F32,
+                _p(stats), rows, C, pos_rows, float(eps), _stream(x))), "wm2f_add_layernorm_train_fwd")
+        ctx.save_for_backward(x, res, gamma, stats)
+        ctx.pos_shape = None if pos is None else tuple(pos.shape)
+        ctx.pos_needs_grad = pos is not None and pos.requires_grad
+        outs = (y,) + ((y_lp,) if want_lp else ()) + ((yp,) if yp is not None else ())
+        ctx.layout = (want_lp, yp is not None)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, res, gamma, stats = ctx.saved_tensors
+        want_lp, has_yp = ctx.layout
+        gy = grads[0]
+        gy_lp = grads[1] if want_lp else None
+        gyp = grads[1 + int(want_lp)] if has_yp else None
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if gy is None and gy_lp is None and gyp is None:
+            return (None,) * 8
+        gy = None if gy is None else _req(gy, "grad_y")
+        gy_lp = None if gy_lp is None else _req(gy_lp, "grad_y_bf16", torch.bfloat16)
+        if gyp is not None:
+            gyp = _req(gyp, "grad_y_plus_pos", gyp.dtype)
+        dsum = torch.empty(x.shape, device=x.device, dtype=torch.float32)  # the residual stream's gradient; x's too when x is fp32
+        dx = torch.empty_like(x) if x.dtype == torch.bfloat16 else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        xd = _lib.WM2F_BF16 if x.dtype == torch.bfloat16 else WM2F_F32
+        with torch.cuda.device(x.device):
+            ws = torch.empty(max(16, int(load().wm2f_add_layernorm_train_workspace(rows))), device=x.device, dtype=torch.uint8)
+            check(_timed("add_layernorm_train_bwd", x, lambda: load().wm2f_add_layernorm_train_bwd(
+                _p(x), xd, _p(res), _p(gamma), _p(stats), _p(gy), _p(gy_lp), _p(gyp),
+                _lib.WM2F_BF16 if (gyp is not None and gyp.dtype == torch.bfloat16) else WM2F_F32, _p(dsum), _p(dx), _p(dgamma), _p(dbeta),
+                _p(ws), rows, C, _stream(x))), "wm2f_add_layernorm_train_bwd")
+        gpos = None
+        if ctx.pos_needs_grad and gyp is not None:  # pos is shared by the batch: its gradient is the sum over the images
+            gpos = torch.sum(gyp.reshape(-1, *ctx.pos_shape), 0, dtype=torch.float32)
+        return (dx if dx is not None else dsum), (dsum if res is not None else None), dgamma, dbeta, None, gpos, None, None
+
+
+def add_layernorm_train_applies(x: torch.Tensor, residual: torch.Tensor | None) -> bool:
+    return (x.is_cuda and x.shape[-1] == 256 and x.dtype in (torch.float32, torch.bfloat16)
+            and (residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape)))
+
+
+def add_layernorm_train(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None = None, want_bf16: bool = False,
+                        pos_bf16: bool = False):
+    """Training form of `add_layernorm`: y = LayerNorm(x + residual) (fp32), differentiable, with -- from the same pass -- y in
+    bf16 (`want_bf16`: the next Linear's operand under bf16 autocast) and y + pos (`pos` (rows_per_image, 256): the next
+    layer's `hidden + pos`, in bf16 with `pos_bf16`).  Returns (y, y_bf16 or None, y_plus_pos or None)."""
+    with torch.autocast("cuda", enabled=False):
+        outs = _AddLayerNormTrain.apply(x, residual, gamma, beta, float(eps), pos, bool(want_bf16), bool(pos_bf16))
+    y = outs[0]
+    y_lp = outs[1] if want_bf16 else None
+    yp = outs[1 + int(want_bf16)] if pos is not None else None
+    return y, y_lp, yp
+
+
 def token_linear_applies(x: torch.Tensor, weight: torch.Tensor) -> bool:
     """Shapes wm2f_token_linear_fwd is built for: fp32 on a GPU, N in {256, 288}, K a multiple of 64, x / out below 2 GiB."""
     N, K = weight.shape
