@@ -144,28 +144,25 @@ __global__ __launch_bounds__(256) void add_layernorm_train_bwd_kernel(LnBwdArgs 
   }
 }
 
-// dgamma[c] / dbeta[c] = sum over workgroups, in workgroup order
+// dgamma[c] / dbeta[c] = sum over the workgroups' partials in a FIXED order: one workgroup per output (512 of them), thread t adds
+// partials t, t + 256, ... in ascending order, then the 256 sums are added pairwise in a fixed tree through LDS.  (Eight workgroups
+// walking 2 688 partials each were latency-bound: 138 us.)
 __global__ __launch_bounds__(256) void add_layernorm_train_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                                          float* __restrict__ dbeta, int blocks) {
-  __shared__ float part[8][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;  // 4 groups of blocks per 64 outputs (of 512)
-  float s0 = 0.f, s1 = 0.f;
-  int i = grp;
-  for (; i + 4 < blocks; i += 8) {
-    s0 += ws[(size_t)i * 512 + c];
-    s1 += ws[(size_t)(i + 4) * 512 + c];
-  }
-  for (; i < blocks; i += 4) s0 += ws[(size_t)i * 512 + c];
-  part[grp][threadIdx.x & 63] = s0;
-  part[4 + grp][threadIdx.x & 63] = s1;
+  __shared__ float part[256];
+  const int c = blockIdx.x, t = threadIdx.x;  // c in [0, 512): dgamma 0..255, dbeta 256..511
+  float s = 0.f;
+  for (int i = t; i < blocks; i += 256) s += ws[(size_t)i * 512 + c];
+  part[t] = s;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
-    const int o = blockIdx.x * 64 + threadIdx.x;
-    if (o < 256) dgamma[o] = t;
-    else dbeta[o - 256] = t;
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (t < w) part[t] += part[t + w];
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (c < 256) dgamma[c] = part[0];
+    else dbeta[c - 256] = part[0];
   }
 }
 
@@ -213,7 +210,7 @@ extern "C" int wm2f_add_layernorm_train_bwd(const void* x, int x_dtype, const vo
   const int blocks = (int)ceil_div64(rows, kLnRowsPerBlock);
   hipLaunchKernelGGL(add_layernorm_train_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   WM2F_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(add_layernorm_train_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+  hipLaunchKernelGGL(add_layernorm_train_reduce_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                      (float*)grad_gamma, (float*)grad_beta, blocks);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;

@@ -304,17 +304,17 @@ __global__ __launch_bounds__(kThreadsW) void token_wgrad_f32_kernel(WgradArgs a)
   }
 }
 
-// dW[n][k] = sum over splits of the partial tiles, db likewise -- in a FIXED order (deterministic): a workgroup owns 32
-// consecutive float4 of one dW row; its 8 thread rows each add every 8th split in ascending order, and the 8 sums are added
+// dW[n][k] = sum over splits of the partial tiles, db likewise -- in a FIXED order (deterministic): a workgroup owns 16
+// consecutive float4 of one dW row; its 16 thread rows each add every 16th split in ascending order, and the 16 sums are added
 // in thread-row order through LDS.  (One thread per output looping over 256 partials 256 KiB apart read at 0.7 TB/s.)
-constexpr int kRedGroups = 8;
+constexpr int kRedGroups = 16, kRedCols = 16;  // 256 threads = 16 float4 positions x 16 split groups
 __global__ __launch_bounds__(256) void token_wgrad_reduce_kernel(const float* __restrict__ ws_w, const float* __restrict__ ws_b,
                                                                   float* __restrict__ dw, float* __restrict__ db, int N, int K,
                                                                   int cbk, int splits) {
-  __shared__ f32x4 part[kRedGroups][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int kq = K / 4, segs = (kq + 31) / 32;  // 32-float4 segments per row
-  const int n = blockIdx.x / segs, k4 = (blockIdx.x - n * segs) * 32 + tx;
+  __shared__ f32x4 part[kRedGroups][kRedCols];
+  const int tx = threadIdx.x & (kRedCols - 1), ty = threadIdx.x / kRedCols;
+  const int kq = K / 4, segs = (kq + kRedCols - 1) / kRedCols;  // 16-float4 segments per row
+  const int n = blockIdx.x / segs, k4 = (blockIdx.x - n * segs) * kRedCols + tx;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (n < N && k4 < kq) {
     const int k = k4 * 4;
@@ -418,7 +418,7 @@ extern "C" int wm2f_token_wgrad_bf16(const void* dy, const void* x, void* dw, vo
   }
   hipLaunchKernelGGL(token_wgrad_bf16_kernel, dim3(p.splits, p.cbn * p.cbk), dim3(kThreadsW), 4 * kImgBytes, (hipStream_t)stream, a);
   WM2F_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)(N * ((K / 4 + 31) / 32))), dim3(256), 0, (hipStream_t)stream, a.ws_w,
+  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)(N * ((K / 4 + kRedCols - 1) / kRedCols))), dim3(256), 0, (hipStream_t)stream, a.ws_w,
                      a.ws_b, (float*)dw, (float*)db, N, K, p.cbk, p.splits);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
@@ -456,7 +456,7 @@ extern "C" int wm2f_token_wgrad_f32(const void* dy, const void* x, void* dw, voi
   }
   hipLaunchKernelGGL(token_wgrad_f32_kernel, dim3(p.splits, p.cbn * p.cbk), dim3(kThreadsW), 4 * kImgBytes32, (hipStream_t)stream, a);
   WM2F_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)(N * ((K / 4 + 31) / 32))), dim3(256), 0, (hipStream_t)stream, a.ws_w,
+  hipLaunchKernelGGL(token_wgrad_reduce_kernel, dim3((unsigned)(N * ((K / 4 + kRedCols - 1) / kRedCols))), dim3(256), 0, (hipStream_t)stream, a.ws_w,
                      a.ws_b, (float*)dw, (float*)db, N, K, p.cbk, p.splits);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
