@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     const int ah = (o.h * (NL * P * 2) + j * 2) * 4, bh = (o.h * (NL * P) + j) * 4;
 #pragma unroll
     for (int t2 = 0; t2 < kPasses; ++t2) {
-      const int q = o.qrow[t2];
+      int q = o.qrow[t2];
+      if (MODE == 8) q = o.qrow[0] & ~1023;  // (profiling build, timing ablation: every operand load from one hot record -- same instructions, L2 latency)
       const int a_off = (int)__umul24((unsigned)q, (unsigned)a_row) + ah;
       const int b_off = (int)__umul24((unsigned)q, (unsigned)b_row) + bh;
       if (kLanes) {
@@ -1569,7 +1570,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   sg.step_h = sg.wg_per_xcd % (heads * split);
   sg.step_tx = sg.step_ty = 0;
   // slab order (lanes bit 2; profiling build: modes 800-803, bit 0 / 1 = non-temporal operand loads / output stores)
-  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 817));
+  const bool slab = exact && FUSED && (lanes & 1) && !half && ((lanes & 4) || (mode >= 800 && mode <= 820));
   if (slab) {
     const int n_tiles = g.tiles_x * g.tiles_y;
     sg.step_h = sg.wg_per_xcd / n_tiles;
@@ -1603,6 +1604,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
     if (mode == 807 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 7, 0, 8, true, 9 + 128>;
     // timing ablations of the slab-order kernel (OUTPUTS NOT VALID): 814 no LDS reads, 815 no window DMA, 816 no operand loads / stores
     if (mode == 817 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 9 + 128 + 2>;      // slab + round-1 loader schedule
+    if (mode == 820 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 8, 0, 8, true, 9 + 128>;  // ablation: operand loads from one hot record
     if (mode == 814 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 4, 0, 8, true, 9 + 128>;
     if (mode == 815 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 5, 0, 8, true, 9 + 128>;
     if (mode == 816 && all_full) kfn = msdeform_stream_fwd_kernel<FUSED, 6, 0, 8, true, 9 + 128>;
