@@ -257,6 +257,16 @@ int wm2f_matcher_cost_levels(const void* const* mask_levels, const void* class_l
                              int w, int Ht, int Wt, int P, int Tmax, float w_class, float w_mask, float w_dice,
                              void* stream);
 
+/* ---- linear sum assignment on the device (HF:474: scipy.optimize.linear_sum_assignment on a host copy of each cost matrix) ----
+ *   cost    (problems, Q, Tmax) fp32 -- wm2f_matcher_cost's output, problems = levels x B, image = problem % B
+ *   counts  (B) int32, DEVICE: targets of each image (its valid columns)
+ *   rows / cols (problems, Tcap) int32: the min(Q, T) matched (query, target) pairs of each problem, sorted by query -- exactly
+ *           what scipy returns for cost[:, :T] (entries beyond min(Q, T) are not written; Tcap >= max over images of min(Q, T_b)).
+ * scipy's own shortest-augmenting-path algorithm with its arithmetic (float64), scan order, tie rule and output order, one wave
+ * per problem: bit-identical indices, ties included (tests).  Sides up to 1024; larger returns WM2F_EUNSUPPORTED. */
+int wm2f_lsa_batched(const void* cost, const void* counts, void* rows, void* cols, int problems, int B, int Q, int Tmax, int Tcap,
+                     void* stream);
+
 /* ---- point sampling (shared by the loss, HF:245-274) ----------------------------------------
  *   feat (N, H, W) fp32 or uint8 (feat_dtype 0 / 1); pts (M, P, 2); out (M, P) fp32.
  *   map_index: int32 [M] -- row m samples feat[map_index[m]] (matched prediction / target maps are
@@ -283,7 +293,10 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
  *                       y (rows, 256) fp32 = LayerNorm(x + residual) * gamma + beta;   x fp32 or bf16 (x_dtype), residual fp32 or NULL
  *                       y_bf16      NULL, or y rounded to bf16 (the next Linear's operand under bf16 autocast)
  *                       y_plus_pos  NULL, or y + pos[row % pos_rows] in yp_dtype (fp32 / bf16)
- *                       stats (rows, 2) fp32 = (mean, rstd) for the backward.
+ *                       stats (rows, 2) fp32 = (mean, rstd) for the backward;
+ *                       clamp > 0: y is limited to [-clamp, clamp], NaN left as it is -- the overflow guard of HF:1090-1093
+ *                       (clamp to finfo.max - 1000 when a value is not finite) without the host synchronisation its `if` costs:
+ *                       on finite values the clamp is the identity, so applying it always is the same function.
  *                     Backward: the gradients of the three outputs (any of them NULL) are summed in registers;
  *                       grad_sum (rows, 256) fp32 = d loss / d (x + residual) (NULL: not written), grad_x the same in x's dtype
  *                       (NULL: not written), grad_gamma / grad_beta (256) fp32 -- per-workgroup partial sums over fixed row
@@ -293,7 +306,7 @@ int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, c
 int64_t wm2f_add_layernorm_train_workspace(int64_t rows);
 int wm2f_add_layernorm_train_fwd(const void* x, int x_dtype, const void* residual, const void* gamma, const void* beta,
                                  const void* pos, void* y, void* y_bf16, void* y_plus_pos, int yp_dtype, void* stats,
-                                 int64_t rows, int C, int64_t pos_rows, float eps, void* stream);
+                                 int64_t rows, int C, int64_t pos_rows, float eps, float clamp, void* stream);
 int wm2f_add_layernorm_train_bwd(const void* x, int x_dtype, const void* residual, const void* gamma, const void* stats,
                                  const void* grad_y, const void* grad_y_bf16, const void* grad_y_plus_pos, int gyp_dtype,
                                  void* grad_sum, void* grad_x, void* grad_gamma, void* grad_beta, void* workspace,

@@ -6,6 +6,7 @@ import os
 import re
 
 import pytest
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -251,3 +252,87 @@ def test_dependency_processor_consumes_the_output_object():
     for i, r in enumerate(res):
         assert torch.equal(r["segmentation"].to(torch.int16), torch.from_numpy(g[f"seg_mixed_{i}"]))
         assert [s["label_id"] for s in r["segments_info"]] == [s["label_id"] for s in info["mixed"]["segments_info"][i]]
+
+
+def _lsa_transcription(cost):
+    """The steps of csrc/lsa.hip (= scipy's rectangular_lsap.cpp) in plain Python: shortest augmenting paths in float64, `remaining`
+    filled in reverse and compacted by swap-with-last, the tie rule (a free column wins among equal shortest-path costs), output
+    sorted by row, fewer columns than rows solved transposed."""
+    cost = np.asarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    transpose = nc < nr
+    if transpose:
+        cost = cost.T.copy()
+        nr, nc = nc, nr
+    u, v, spc = np.zeros(nr), np.zeros(nc), np.empty(nc)
+    path, col4row, row4col = np.full(nc, -1), np.full(nr, -1), np.full(nc, -1)
+    SR, SC, remaining = np.zeros(nr, bool), np.zeros(nc, bool), np.empty(nc, int)
+    for cur in range(nr):
+        min_val, i, num_remaining, sink = 0.0, cur, nc, -1
+        remaining[:] = nc - 1 - np.arange(nc)
+        SR[:] = False
+        SC[:] = False
+        spc[:] = np.inf
+        while sink == -1:
+            index, lowest = -1, np.inf
+            SR[i] = True
+            for it in range(num_remaining):
+                j = remaining[it]
+                r = min_val + cost[i, j] - u[i] - v[j]
+                if r < spc[j]:
+                    path[j], spc[j] = i, r
+                if spc[j] < lowest or (spc[j] == lowest and row4col[j] == -1):
+                    lowest, index = spc[j], it
+            min_val = lowest
+            j = remaining[index]
+            if row4col[j] == -1:
+                sink = j
+            else:
+                i = row4col[j]
+            SC[j] = True
+            num_remaining -= 1
+            remaining[index] = remaining[num_remaining]
+        u[cur] += min_val
+        for i2 in range(nr):
+            if SR[i2] and i2 != cur:
+                u[i2] += min_val - spc[col4row[i2]]
+        for j2 in range(nc):
+            if SC[j2]:
+                v[j2] -= min_val - spc[j2]
+        j = sink
+        while True:
+            i2 = path[j]
+            row4col[j] = i2
+            col4row[i2], j = j, col4row[i2]
+            if i2 == cur:
+                break
+    if transpose:
+        order = np.argsort(col4row, kind="stable")
+        return col4row[order], order
+    return np.arange(nr), col4row
+
+
+def test_lsa_transcription_equals_scipy():
+    """The algorithm the device solver implements (csrc/lsa.hip) IS scipy's: its Python transcription returns scipy's indices on
+    random matrices and on tie-heavy integer matrices (where the tie rule and the scan order decide), both orientations."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(0)
+    for trial in range(1200):
+        nr, nc = rng.integers(1, 20), rng.integers(1, 20)
+        kind = trial % 4
+        if kind == 0:
+            c = rng.standard_normal((nr, nc))
+        elif kind == 1:
+            c = rng.integers(0, 3, (nr, nc)).astype(float)
+        elif kind == 2:
+            c = rng.integers(0, 2, (nr, nc)).astype(float) * 5
+        else:
+            c = rng.standard_normal((nr, nc)).astype(np.float32).astype(float).round(1)
+        r0, c0 = linear_sum_assignment(c)
+        r1, c1 = _lsa_transcription(c)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (trial, c)
+    for _ in range(20):
+        c = rng.standard_normal((100, 16)).astype(np.float32)
+        r0, c0 = linear_sum_assignment(c)
+        r1, c1 = _lsa_transcription(c)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1)

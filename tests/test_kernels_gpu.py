@@ -574,6 +574,30 @@ def test_k2_backward(ops, B, H, Q, N, D, use_mask):
 
 
 # ----------------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("NL,B,Q,Tmax,kind", [(3, 4, 100, 16, "randn"), (2, 3, 100, 16, "ties"), (1, 5, 10, 24, "randn"), (2, 2, 7, 7, "ties"),
+                                              (1, 3, 200, 40, "randn"), (1, 2, 1, 5, "randn"), (1, 2, 130, 1, "randn"), (2, 2, 64, 65, "ties"),
+                                              (10, 16, 100, 16, "randn")])
+def test_lsa_batched_equals_scipy(ops, NL, B, Q, Tmax, kind):
+    """ops.lsa_batched (the assignment on the device, csrc/lsa.hip) returns scipy.optimize.linear_sum_assignment's indices BIT for
+    BIT on every (level, image) problem: random costs, tie-heavy small-integer costs (the tie rule and the scan order decide),
+    fewer targets than queries (solved transposed) and more, a different target count per image, single rows / columns."""
+    from scipy.optimize import linear_sum_assignment
+    g = torch.Generator().manual_seed(NL * 1000 + Q + Tmax)
+    if kind == "randn":
+        cost = torch.randn(NL, B, Q, Tmax, generator=g)
+    else:
+        cost = torch.randint(0, 3, (NL, B, Q, Tmax), generator=g).float()
+    counts = [int(x) for x in torch.randint(1, Tmax + 1, (B,), generator=g)]
+    counts[0] = Tmax
+    matched = [min(Q, c) for c in counts]
+    rows, cols = ops.lsa_batched(dev(cost), dev(torch.tensor(counts, dtype=torch.int32)), max(matched))
+    rows, cols = rows.cpu().numpy(), cols.cpu().numpy()
+    for l in range(NL):
+        for b in range(B):
+            r, c = linear_sum_assignment(cost[l, b, :, :counts[b]].numpy())
+            assert np.array_equal(rows[l, b, :matched[b]], r) and np.array_equal(cols[l, b, :matched[b]], c), (l, b)
+
+
 def test_k4_golden_cost_and_indices(ops):
     g = load_golden("k4_matcher.npz")
     wc, wm, wd = [float(x) for x in g["weights"]]

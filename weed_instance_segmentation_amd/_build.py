@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libwm2f.so")
 # environment knobs of K2 / K3 (include/wm2f_prof.h).  tools/ load it; the product never does.
 OBJ_PROF = os.path.join(CSRC, "build_prof")
 LIB_PROF = os.path.join(HERE, "libwm2f_prof.so")
-SOURCES = ["api.hip", "msdeform.hip", "msdeform_tiled.hip", "msdeform_quad.hip", "msdeform_tiled_bwd.hip", "mask_einsum.hip", "mask_einsum_bf16.hip", "token_gemm.hip", "token_wgrad.hip", "layernorm_train.hip", "attn_mask.hip", "masked_xattn.hip", "matcher.hip", "fused_elementwise.hip", "postprocess.hip", "mask_loss.hip"]
+SOURCES = ["api.hip", "msdeform.hip", "msdeform_tiled.hip", "msdeform_quad.hip", "msdeform_tiled_bwd.hip", "mask_einsum.hip", "mask_einsum_bf16.hip", "token_gemm.hip", "token_wgrad.hip", "layernorm_train.hip", "attn_mask.hip", "masked_xattn.hip", "matcher.hip", "lsa.hip", "fused_elementwise.hip", "postprocess.hip", "mask_loss.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "msdeform_tiled.h"), os.path.join(os.path.dirname(HERE), "include", "wm2f.h"),
            os.path.join(os.path.dirname(HERE), "include", "wm2f_prof.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -65,10 +65,11 @@ SIGNATURES = {
                                   c_float, c_float, c_float, _P]),
     "wm2f_matcher_cost_levels": (c_int, [POINTER(c_void_p), _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                          _I, _I, _I, c_float, c_float, c_float, _P]),
+    "wm2f_lsa_batched": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_bias_act": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_add_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _I, c_int64, c_float, _P]),
     "wm2f_add_layernorm_train_workspace": (c_int64, [c_int64]),
-    "wm2f_add_layernorm_train_fwd": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, c_int64, _I, c_int64, c_float, _P]),
+    "wm2f_add_layernorm_train_fwd": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, c_int64, _I, c_int64, c_float, c_float, _P]),
     "wm2f_add_layernorm_train_bwd": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, c_int64, _I, _P]),
     "wm2f_token_linear_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _I, _I, _I, c_int64, c_float, _I, _P]),
     "wm2f_token_wgrad_workspace": (c_int64, [c_int64, _I, _I]),

@@ -55,7 +55,7 @@ struct LnFwdArgs {
   void* yp;           // (rows, 256) = y + pos, bf16 / fp32, or null
   float* stats;       // (rows, 2) = (mean, rstd)
   long long rows, pos_rows;
-  float eps;
+  float eps, clamp;  // clamp > 0: y is limited to [-clamp, clamp] (NaN stays NaN) -- the encoder layer's overflow guard, HF:1090-1093
   int x_bf16, yp_bf16;
 };
 
@@ -74,6 +74,13 @@ __global__ __launch_bounds__(256) void add_layernorm_train_fwd_kernel(LnFwdArgs 
   const float rstd = rsqrtf(var + a.eps);
   const float4 g = reinterpret_cast<const float4*>(a.gamma)[lane], b = reinterpret_cast<const float4*>(a.beta)[lane];
   float4 o = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+  if (a.clamp > 0.f) {  // comparisons, not fmin / fmax: a NaN must stay a NaN, as torch.clamp leaves it
+    const float c = a.clamp;
+    o.x = o.x > c ? c : (o.x < -c ? -c : o.x);
+    o.y = o.y > c ? c : (o.y < -c ? -c : o.y);
+    o.z = o.z > c ? c : (o.z < -c ? -c : o.z);
+    o.w = o.w > c ? c : (o.w < -c ? -c : o.w);
+  }
   reinterpret_cast<float4*>(a.y + row * 256)[lane] = o;
   if (a.y_lp != nullptr) st4(a.y_lp, 1, row, lane, o);
   if (a.yp != nullptr) {
@@ -179,7 +186,7 @@ extern "C" int64_t wm2f_add_layernorm_train_workspace(int64_t rows) {
 
 extern "C" int wm2f_add_layernorm_train_fwd(const void* x, int x_dtype, const void* residual, const void* gamma, const void* beta,
                                             const void* pos, void* y, void* y_bf16, void* y_plus_pos, int yp_dtype, void* stats,
-                                            int64_t rows, int C, int64_t pos_rows, float eps, void* stream) {
+                                            int64_t rows, int C, int64_t pos_rows, float eps, float clamp, void* stream) {
   const char* who = "wm2f_add_layernorm_train_fwd";
   WM2F_REQUIRE(x && gamma && beta && y && stats && rows > 0, "%s: null pointer / no rows", who);
   WM2F_REQUIRE(C == 256, "%s: C = %d (built for 256)", who, C);
@@ -188,7 +195,7 @@ extern "C" int wm2f_add_layernorm_train_fwd(const void* x, int x_dtype, const vo
   LnFwdArgs a;
   a.x = x; a.res = (const float*)residual; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.pos = (const float*)pos;
   a.y = (float*)y; a.y_lp = y_bf16; a.yp = y_plus_pos; a.stats = (float*)stats;
-  a.rows = rows; a.pos_rows = pos_rows > 0 ? pos_rows : 1; a.eps = eps; a.x_bf16 = x_dtype == WM2F_BF16; a.yp_bf16 = yp_dtype == WM2F_BF16;
+  a.rows = rows; a.pos_rows = pos_rows > 0 ? pos_rows : 1; a.eps = eps; a.clamp = clamp; a.x_bf16 = x_dtype == WM2F_BF16; a.yp_bf16 = yp_dtype == WM2F_BF16;
   hipLaunchKernelGGL(add_layernorm_train_fwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, a);
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;

@@ -4,9 +4,12 @@ Mirrors `Mask2FormerHungarianMatcher` (HF:378-481) and `Mask2FormerLoss` (HF:485
 same sampling scheme, same weights, same result, but organised for one MI355X per process:
 
   * the cost matrices of EVERY prediction level and EVERY image come from one batched kernel
-    call (K4, ops.matcher_cost) and reach the host in ONE copy; the reference syncs once per
-    (image, level) -- B x 10 times per step (HF:474);
-  * the linear-sum-assignment solver stays scipy on the host, exactly as in the reference;
+    call (K4, ops.matcher_cost); the reference syncs once per (image, level) -- B x 10 times per
+    step (HF:474);
+  * the linear sum assignment runs on the device too (ops.lsa_batched: scipy's own algorithm, arithmetic
+    and tie rule -- bit-identical indices), so the loss has NO host synchronisation: the index tensors
+    of every loss term are built by device ops from the solver's output (`DeviceIndices`).  scipy on a
+    host copy remains the route for matrices beyond the kernel's size and for the per-level loss path;
   * point sampling of predictions / targets uses the HIP sampler (ops.point_sample).
 
 Random points: the dependency draws from torch's global generator in call order (HF:455, :705,
@@ -70,6 +73,60 @@ class ReplayPointProvider:
         return self.draws[self._slot(level) + self.batch + 1].to(self.device)
 
 
+class DeviceIndices:
+    """The assignment of every (level, image) as the device solver left it: rows / cols (NL, B, t_cap) int32 -- the matched
+    (query, target) pairs sorted by query, `matched[b]` = min(Q, T_b) of them valid -- plus the flat views the loss terms
+    index with, all built by device ops (no synchronisation).  Iterating / indexing it like the host form (`[level][image]` ->
+    (rows, cols) int64 CPU tensors) copies to the host on first use: for callers and tests, not for the loss."""
+
+    def __init__(self, rows: torch.Tensor, cols: torch.Tensor, matched: list[int]):
+        self.rows, self.cols, self.matched = rows, cols, [int(m) for m in matched]
+        NL, B, cap = rows.shape
+        dev = rows.device
+        b_idx = torch.cat([torch.full((m,), i, dtype=torch.int64) for i, m in enumerate(self.matched)]) if sum(self.matched) else torch.zeros(0, dtype=torch.int64)
+        slot = torch.cat([torch.arange(m) for m in self.matched]) if sum(self.matched) else torch.zeros(0, dtype=torch.int64)
+        self.b_idx, self.slot = b_idx.to(dev), slot.to(dev)     # (M,) image / position in the image's matched list
+        flat = (b_idx * cap + slot).to(dev)
+        self.q = rows.reshape(NL, B * cap)[:, flat].long()      # (NL, M) matched query
+        self.t = cols.reshape(NL, B * cap)[:, flat].long()      # (NL, M) matched target (index inside its image)
+        self._host = None
+
+    @property
+    def M(self) -> int:
+        return int(self.b_idx.numel())
+
+    def host(self):
+        if self._host is None:
+            r, c = self.rows.cpu().long(), self.cols.cpu().long()
+            self._host = [[(r[l, b, :m].clone(), c[l, b, :m].clone()) for b, m in enumerate(self.matched)] for l in range(r.shape[0])]
+        return self._host
+
+    def __len__(self):
+        return self.rows.shape[0]
+
+    def __getitem__(self, level):
+        return self.host()[level]
+
+    def __iter__(self):
+        return iter(self.host())
+
+
+class _LevelView:
+    """`indices[level]` of a DeviceIndices for callers that iterate images (the model's `matched_indices`): lazy host copy."""
+
+    def __init__(self, di: DeviceIndices, level: int):
+        self.di, self.level = di, level
+
+    def __iter__(self):
+        return iter(self.di.host()[self.level])
+
+    def __len__(self):
+        return len(self.di.matched)
+
+    def __getitem__(self, i):
+        return self.di.host()[self.level][i]
+
+
 class Mask2FormerLoss(nn.Module):
     def __init__(self, config, weight_dict):
         super().__init__()
@@ -87,6 +144,7 @@ class Mask2FormerLoss(nn.Module):
         # predictions; this attribute = False restores the dense route (A/B runs and tests)
         self.matched_row_masks = True
         self.sort_matcher_points = True  # see match()
+        self.device_lsa = True  # ops.lsa_batched instead of scipy on a host copy (same indices); False: the host route
         self.cost_class, self.cost_mask, self.cost_dice = config.class_weight, config.mask_weight, config.dice_weight
         self.world_size_fn = None  # set by parallel.DataParallelEngine: all-reduces num_masks (HF:781-794)
 
@@ -109,7 +167,12 @@ class Mask2FormerLoss(nn.Module):
             points = torch.gather(points, 2, key.argsort(dim=2)[..., None].expand(-1, -1, -1, 2)).contiguous()
         cost = ops.matcher_cost(ml if NL <= 16 else torch.stack(ml), cl.float(), tgt, counts, cls, points, self.cost_class,
                                 self.cost_mask, self.cost_dice)
-        cost = cost.cpu().numpy()  # the ONE device->host sync of the step
+        Q = cost.shape[2]
+        if self.device_lsa and cost.is_cuda and Q <= 1024 and cost.shape[3] <= 1024 and min(counts) > 0:
+            matched = [min(Q, c) for c in counts]
+            rows, cols = ops.lsa_batched(cost, torch.tensor(counts, dtype=torch.int32).to(cost.device, non_blocking=True), max(matched))
+            return DeviceIndices(rows, cols, matched)
+        cost = cost.cpu().numpy()  # the host route: ONE device->host sync of the step
         indices = []
         for l in range(NL):
             per = []
@@ -144,12 +207,19 @@ class Mask2FormerLoss(nn.Module):
         B, Q, C1 = all_classes[0].shape
         dev = all_classes[0].device
         logits = torch.stack([all_classes[lvl] for lvl in order])  # (NL, B, Q, C1): tiny
-        li = torch.cat([torch.full((sum(int(s.numel()) for s, _ in indices[lvl]),), n, dtype=torch.int64) for n, lvl in enumerate(order)])
-        bi = torch.cat([torch.full_like(s, i) for lvl in order for i, (s, _) in enumerate(indices[lvl])])
-        si = torch.cat([s for lvl in order for s, _ in indices[lvl]])
-        ti = torch.cat([t + offsets[i] for lvl in order for i, (_, t) in enumerate(indices[lvl])])
         target = torch.full((len(order), B, Q), self.num_labels, dtype=torch.int64, device=dev)
-        target[li.to(dev), bi.to(dev), si.to(dev)] = cls[ti.to(dev)]
+        if isinstance(indices, DeviceIndices):  # device ops only
+            od = torch.as_tensor(order, device=dev)
+            M = indices.M
+            li = torch.arange(len(order), device=dev)[:, None].expand(-1, M)
+            off = torch.as_tensor(offsets[:-1], device=dev)[indices.b_idx]
+            target[li, indices.b_idx[None].expand(len(order), -1), indices.q[od]] = cls[indices.t[od] + off[None]]
+        else:
+            li = torch.cat([torch.full((sum(int(s.numel()) for s, _ in indices[lvl]),), n, dtype=torch.int64) for n, lvl in enumerate(order)])
+            bi = torch.cat([torch.full_like(s, i) for lvl in order for i, (s, _) in enumerate(indices[lvl])])
+            si = torch.cat([s for lvl in order for s, _ in indices[lvl]])
+            ti = torch.cat([t + offsets[i] for lvl in order for i, (_, t) in enumerate(indices[lvl])])
+            target[li.to(dev), bi.to(dev), si.to(dev)] = cls[ti.to(dev)]
         nll = F.cross_entropy(logits.reshape(-1, C1).float(), target.reshape(-1), weight=self.empty_weight, reduction="none")
         wts = self.empty_weight[target.reshape(-1)]
         return nll.view(len(order), -1).sum(1) / wts.view(len(order), -1).sum(1)
@@ -199,13 +269,18 @@ class Mask2FormerLoss(nn.Module):
         B = pix.shape[0]
         NL = len(order)
         dev = pix.device
-        counts = [int(s.numel()) for s, _ in indices[order[0]]]
+        dev_idx = isinstance(indices, DeviceIndices)
+        counts = indices.matched if dev_idx else [int(s.numel()) for s, _ in indices[order[0]]]
         # whole multiples of 4 rows per level: the hand-written K3 backward wants Q % 4 == 0 (an odd count would silently take
         # the library bmm pair); the extra rows are zero embeddings that no index points at
         t_max = (max(max(counts), 1) + 3) // 4 * 4
-        b_idx = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
-        t_idx = torch.cat([torch.arange(c) for c in counts]).to(dev)
-        q_idx = torch.stack([torch.cat([s for s, _ in indices[lvl]]) for lvl in order]).to(dev)  # (NL, M)
+        if dev_idx:
+            b_idx, t_idx = indices.b_idx, indices.slot
+            q_idx = indices.q[torch.as_tensor(order, device=dev)]  # (NL, M)
+        else:
+            b_idx = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
+            t_idx = torch.cat([torch.arange(c) for c in counts]).to(dev)
+            q_idx = torch.stack([torch.cat([s for s, _ in indices[lvl]]) for lvl in order]).to(dev)  # (NL, M)
         h_m = torch.stack([inter[lvl][b_idx, q_idx[n]] for n, lvl in enumerate(order)])            # (NL, M, d)
         emb_m = embedder(h_m)                                                                     # (NL, M, C)
         C = emb_m.shape[-1]
@@ -231,8 +306,13 @@ class Mask2FormerLoss(nn.Module):
         dev = all_masks[0].device
         B, Q, h, w = all_masks[0].shape
         NL, P = len(order), self.num_points
-        pred_idx = torch.stack([torch.cat([s + i * Q for i, (s, _) in enumerate(indices[lvl])]) for lvl in order])
-        tgt_idx = torch.stack([torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices[lvl])]) for lvl in order])
+        if isinstance(indices, DeviceIndices):  # device ops only
+            od = torch.as_tensor(order, device=dev)
+            pred_idx = indices.q[od] + indices.b_idx[None] * Q
+            tgt_idx = indices.t[od] + torch.as_tensor(offsets[:-1], device=dev)[indices.b_idx][None]
+        else:
+            pred_idx = torch.stack([torch.cat([s + i * Q for i, (s, _) in enumerate(indices[lvl])]) for lvl in order])
+            tgt_idx = torch.stack([torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices[lvl])]) for lvl in order])
         M = int(pred_idx.shape[1])
         if M == 0:
             z = torch.stack([all_masks[lvl].sum() * 0.0 for lvl in order])
@@ -285,11 +365,12 @@ class Mask2FormerLoss(nn.Module):
         num_masks = self._num_masks(counts, dev)
         losses = {}
         order = [NL - 1] + list(range(NL - 1))  # HF:762-777: final level first, then aux 0..n-2
-        same_m = len({sum(int(s.numel()) for s, _ in indices[lvl]) for lvl in order}) == 1
+        dev_idx = isinstance(indices, DeviceIndices)
+        same_m = dev_idx or len({sum(int(s.numel()) for s, _ in indices[lvl]) for lvl in order}) == 1
         batched = self.batched_levels and same_m and NL <= 16
         if batched:
             rows = matched_rows if (matched_rows is not None and self.matched_row_masks and all_masks[0].is_cuda) else None
-            m_total = sum(int(s.numel()) for s, _ in indices[order[0]])
+            m_total = indices.M if dev_idx else sum(int(s.numel()) for s, _ in indices[order[0]])
             if rows is not None and NL * m_total >= 65536:
                 # the matched-row route folds the levels into ONE map list of NL * M rows, and the point samplers carry the
                 # row in grid.y (< 65536): beyond that (33+ fully matched 200-query images per rank at 10 levels) the dense
@@ -307,4 +388,4 @@ class Mask2FormerLoss(nn.Module):
             losses["loss_mask" + suffix] = lm * self.weight_dict["loss_mask"]
             losses["loss_dice" + suffix] = ld * self.weight_dict["loss_dice"]
             losses["loss_cross_entropy" + suffix] = lc * self.weight_dict["loss_cross_entropy"]
-        return losses, indices[NL - 1]
+        return losses, (_LevelView(indices, NL - 1) if dev_idx else indices[NL - 1])

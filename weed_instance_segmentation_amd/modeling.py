@@ -210,9 +210,13 @@ class PixelDecoderEncoderLayer(nn.Module):
             hidden, h_lp, _ = ops.add_layernorm_train(a, hidden, ln1.weight, ln1.bias, ln1.eps, want_bf16=bf16)
             f = F.relu(ops.linear_tokens(hidden if h_lp is None else h_lp, self.fc1.weight, self.fc1.bias))
             f = ops.linear_tokens(f, self.fc2.weight, self.fc2.bias)
+            # HF:1090-1093 clamps the layer's output to finfo.max - 1000 `if` it holds an inf / NaN -- a host synchronisation per
+            # layer.  On finite values that clamp is the identity and a NaN passes through it, so applying it ALWAYS (inside the
+            # kernel's store) is the same function without the wait.
+            cv = (torch.finfo(torch.float32).max - 1000) if self.training else 0.0
             hidden, h_lp, hp_next = ops.add_layernorm_train(f, hidden, ln2.weight, ln2.bias, ln2.eps, pos=pos if emit_next else None,
-                                                             want_bf16=bf16 and emit_next, pos_bf16=bf16)
-            nxt = (hp_next, h_lp) if emit_next else None
+                                                             want_bf16=bf16 and emit_next, pos_bf16=bf16, clamp=cv)
+            return hidden, ((hp_next, h_lp) if emit_next else None)
         else:
             a = F.dropout(self.self_attn(hidden, pos, ref, level_hw, hp, hidden_lp), self.dropout, self.training)
             hidden = self.self_attn_layer_norm(hidden + a)

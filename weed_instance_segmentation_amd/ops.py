@@ -625,6 +625,22 @@ def matcher_cost(mask_logits, class_logits, tgt_masks, tgt_counts, tgt_classes, 
 
 
 # ----------------------------------------------------------------------------------------- point sampling
+def lsa_batched(cost: torch.Tensor, counts: torch.Tensor, t_cap: int):
+    """Linear sum assignment of every (level, image) cost matrix on the device (HF:474 without the host round trip).
+    cost (NL, B, Q, Tmax) fp32; counts (B) int32 on the device = targets per image.  Returns rows, cols (NL, B, t_cap) int32:
+    the min(Q, T_b) matched (query, target) pairs per problem sorted by query, bit-identical to scipy's
+    linear_sum_assignment(cost[l, b, :, :T_b]); entries beyond min(Q, T_b) are unspecified."""
+    cost = _req(cost, "cost")
+    counts = _req(counts, "counts", torch.int32)
+    NL, B, Q, Tmax = cost.shape
+    rows = torch.empty(NL, B, t_cap, device=cost.device, dtype=torch.int32)
+    cols = torch.empty_like(rows)
+    with torch.cuda.device(cost.device):
+        check(_timed("lsa_batched", cost, lambda: load().wm2f_lsa_batched(_p(cost), _p(counts), _p(rows), _p(cols), NL * B, B, Q, Tmax,
+                                                                        int(t_cap), _stream(cost))), "wm2f_lsa_batched")
+    return rows, cols
+
+
 class _PointSample(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
@@ -716,7 +732,7 @@ class _AddLayerNormTrain(torch.autograd.Function):
     wm2f_add_layernorm_train_*).  Returns (y fp32, y in bf16 or None, y + pos in bf16 / fp32 or None)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, pos, want_lp, yp_bf16):
+    def forward(ctx, x, res, gamma, beta, eps, pos, want_lp, yp_bf16, clamp):
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise TypeError(f"add_layernorm_train: x is {x.dtype}")
         x = _req(x, "x", x.dtype)
@@ -741,7 +757,7 @@ class _AddLayerNormTrain(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(_timed("add_layernorm_train_fwd", x, lambda: load().wm2f_add_layernorm_train_fwd(
                 _p(x), xd, _p(res), _p(gamma), _p(beta), _p(pos), _p(y), _p(y_lp), _p(yp), _lib.WM2F_BF16 if yp_bf16 else WM2F_F32,
-                _p(stats), rows, C, pos_rows, float(eps), _stream(x))), "wm2f_add_layernorm_train_fwd")
+                _p(stats), rows, C, pos_rows, float(eps), float(clamp), _stream(x))), "wm2f_add_layernorm_train_fwd")
         ctx.save_for_backward(x, res, gamma, stats)
         ctx.pos_shape = None if pos is None else tuple(pos.shape)
         ctx.pos_needs_grad = pos is not None and pos.requires_grad
@@ -759,7 +775,7 @@ class _AddLayerNormTrain(torch.autograd.Function):
         C = x.shape[-1]
         rows = x.numel() // C
         if gy is None and gy_lp is None and gyp is None:
-            return (None,) * 8
+            return (None,) * 9
         gy = None if gy is None else _req(gy, "grad_y")
         gy_lp = None if gy_lp is None else _req(gy_lp, "grad_y_bf16", torch.bfloat16)
         if gyp is not None:
@@ -777,7 +793,7 @@ class _AddLayerNormTrain(torch.autograd.Function):
         gpos = None
         if ctx.pos_needs_grad and gyp is not None:  # pos is shared by the batch: its gradient is the sum over the images
             gpos = torch.sum(gyp.reshape(-1, *ctx.pos_shape), 0, dtype=torch.float32)
-        return (dx if dx is not None else dsum), (dsum if res is not None else None), dgamma, dbeta, None, gpos, None, None
+        return (dx if dx is not None else dsum), (dsum if res is not None else None), dgamma, dbeta, None, gpos, None, None, None
 
 
 def add_layernorm_train_applies(x: torch.Tensor, residual: torch.Tensor | None) -> bool:
@@ -786,12 +802,13 @@ def add_layernorm_train_applies(x: torch.Tensor, residual: torch.Tensor | None) 
 
 
 def add_layernorm_train(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None = None, want_bf16: bool = False,
-                        pos_bf16: bool = False):
+                        pos_bf16: bool = False, clamp: float = 0.0):
     """Training form of `add_layernorm`: y = LayerNorm(x + residual) (fp32), differentiable, with -- from the same pass -- y in
     bf16 (`want_bf16`: the next Linear's operand under bf16 autocast) and y + pos (`pos` (rows_per_image, 256): the next
-    layer's `hidden + pos`, in bf16 with `pos_bf16`).  Returns (y, y_bf16 or None, y_plus_pos or None)."""
+    layer's `hidden + pos`, in bf16 with `pos_bf16`).  clamp > 0 limits y to [-clamp, clamp] (NaN untouched; its gradient
+    passes through).  Returns (y, y_bf16 or None, y_plus_pos or None)."""
     with torch.autocast("cuda", enabled=False):
-        outs = _AddLayerNormTrain.apply(x, residual, gamma, beta, float(eps), pos, bool(want_bf16), bool(pos_bf16))
+        outs = _AddLayerNormTrain.apply(x, residual, gamma, beta, float(eps), pos, bool(want_bf16), bool(pos_bf16), float(clamp))
     y = outs[0]
     y_lp = outs[1] if want_bf16 else None
     yp = outs[1 + int(want_bf16)] if pos is not None else None
