@@ -73,6 +73,23 @@ class ReplayPointProvider:
         return self.draws[self._slot(level) + self.batch + 1].to(self.device)
 
 
+_CONST_CACHE: dict = {}
+
+
+def _dev_const(values, device, dtype=torch.int64) -> torch.Tensor:
+    """Small host-known integer tables (level order, per-image offsets and counts, the image / slot of every matched pair) as
+    device tensors, cached by value: a train loop sees the same few target-count patterns again and again, and a host-to-device
+    copy per step -- however small -- is a point where the host can wait for the stream."""
+    key = (tuple(int(v) for v in values), str(device), dtype)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 512:
+            _CONST_CACHE.clear()
+        t = torch.tensor(key[0], dtype=dtype).to(device)
+        _CONST_CACHE[key] = t
+    return t
+
+
 class DeviceIndices:
     """The assignment of every (level, image) as the device solver left it: rows / cols (NL, B, t_cap) int32 -- the matched
     (query, target) pairs sorted by query, `matched[b]` = min(Q, T_b) of them valid -- plus the flat views the loss terms
@@ -83,10 +100,10 @@ class DeviceIndices:
         self.rows, self.cols, self.matched = rows, cols, [int(m) for m in matched]
         NL, B, cap = rows.shape
         dev = rows.device
-        b_idx = torch.cat([torch.full((m,), i, dtype=torch.int64) for i, m in enumerate(self.matched)]) if sum(self.matched) else torch.zeros(0, dtype=torch.int64)
-        slot = torch.cat([torch.arange(m) for m in self.matched]) if sum(self.matched) else torch.zeros(0, dtype=torch.int64)
-        self.b_idx, self.slot = b_idx.to(dev), slot.to(dev)     # (M,) image / position in the image's matched list
-        flat = (b_idx * cap + slot).to(dev)
+        b_list = [i for i, m in enumerate(self.matched) for _ in range(m)]
+        s_list = [k for m in self.matched for k in range(m)]
+        self.b_idx, self.slot = _dev_const(b_list, dev), _dev_const(s_list, dev)  # (M,) image / position in the image's matched list
+        flat = _dev_const([b * cap + k for b, k in zip(b_list, s_list)], dev)
         self.q = rows.reshape(NL, B * cap)[:, flat].long()      # (NL, M) matched query
         self.t = cols.reshape(NL, B * cap)[:, flat].long()      # (NL, M) matched target (index inside its image)
         self._host = None
@@ -170,7 +187,7 @@ class Mask2FormerLoss(nn.Module):
         Q = cost.shape[2]
         if self.device_lsa and cost.is_cuda and Q <= 1024 and cost.shape[3] <= 1024 and min(counts) > 0:
             matched = [min(Q, c) for c in counts]
-            rows, cols = ops.lsa_batched(cost, torch.tensor(counts, dtype=torch.int32).to(cost.device, non_blocking=True), max(matched))
+            rows, cols = ops.lsa_batched(cost, _dev_const(counts, cost.device, torch.int32), max(matched))
             return DeviceIndices(rows, cols, matched)
         cost = cost.cpu().numpy()  # the host route: ONE device->host sync of the step
         indices = []
@@ -184,7 +201,7 @@ class Mask2FormerLoss(nn.Module):
 
     # ---------------------------------------------------------------- per-level losses
     def _num_masks(self, counts, device):
-        n = torch.as_tensor(float(sum(counts)), dtype=torch.float, device=device)
+        n = torch.full((), float(sum(counts)), dtype=torch.float, device=device)  # (a fill, not a host-to-device copy)
         world = 1
         if self.world_size_fn is not None:
             n, world = self.world_size_fn(n)
@@ -209,10 +226,10 @@ class Mask2FormerLoss(nn.Module):
         logits = torch.stack([all_classes[lvl] for lvl in order])  # (NL, B, Q, C1): tiny
         target = torch.full((len(order), B, Q), self.num_labels, dtype=torch.int64, device=dev)
         if isinstance(indices, DeviceIndices):  # device ops only
-            od = torch.as_tensor(order, device=dev)
+            od = _dev_const(order, dev)
             M = indices.M
-            li = torch.arange(len(order), device=dev)[:, None].expand(-1, M)
-            off = torch.as_tensor(offsets[:-1], device=dev)[indices.b_idx]
+            li = _dev_const(range(len(order)), dev)[:, None].expand(-1, M)
+            off = _dev_const(offsets[:-1], dev)[indices.b_idx]
             target[li, indices.b_idx[None].expand(len(order), -1), indices.q[od]] = cls[indices.t[od] + off[None]]
         else:
             li = torch.cat([torch.full((sum(int(s.numel()) for s, _ in indices[lvl]),), n, dtype=torch.int64) for n, lvl in enumerate(order)])
@@ -276,7 +293,7 @@ class Mask2FormerLoss(nn.Module):
         t_max = (max(max(counts), 1) + 3) // 4 * 4
         if dev_idx:
             b_idx, t_idx = indices.b_idx, indices.slot
-            q_idx = indices.q[torch.as_tensor(order, device=dev)]  # (NL, M)
+            q_idx = indices.q[_dev_const(order, dev)]  # (NL, M)
         else:
             b_idx = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
             t_idx = torch.cat([torch.arange(c) for c in counts]).to(dev)
@@ -307,9 +324,9 @@ class Mask2FormerLoss(nn.Module):
         B, Q, h, w = all_masks[0].shape
         NL, P = len(order), self.num_points
         if isinstance(indices, DeviceIndices):  # device ops only
-            od = torch.as_tensor(order, device=dev)
+            od = _dev_const(order, dev)
             pred_idx = indices.q[od] + indices.b_idx[None] * Q
-            tgt_idx = indices.t[od] + torch.as_tensor(offsets[:-1], device=dev)[indices.b_idx][None]
+            tgt_idx = indices.t[od] + _dev_const(offsets[:-1], dev)[indices.b_idx][None]
         else:
             pred_idx = torch.stack([torch.cat([s + i * Q for i, (s, _) in enumerate(indices[lvl])]) for lvl in order])
             tgt_idx = torch.stack([torch.cat([t + offsets[i] for i, (_, t) in enumerate(indices[lvl])]) for lvl in order])
