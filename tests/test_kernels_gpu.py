@@ -1056,7 +1056,9 @@ def test_k1_streaming_kernel_on_pyramids_that_are_not_1_2_4(ops, shapes, B):
 @pytest.mark.parametrize("NL,N,M,H,W,P", [(3, 7, 5, 64, 64, 300),      # one band per map
                                           (2, 6, 4, 150, 256, 1000),   # 64-row bands, the last one ragged, points on band seams
                                           (1, 9, 9, 33, 50, 257),      # pixel count not a multiple of 4
-                                          (4, 3, 3, 8, 12, 40)])
+                                          (4, 3, 3, 8, 12, 40),
+                                          # >= 4096 points per map: the forward's LDS band form (two bands), square / odd / ragged maps
+                                          (2, 5, 4, 256, 256, 5000), (1, 4, 3, 101, 77, 4100), (2, 3, 3, 150, 256, 4096)])
 def test_point_sample_levels_forward_and_both_backwards(ops, NL, N, M, H, W, P):
     """sample_point (HF:245-274 = grid_sample, bilinear, align_corners False, zero padding) over level maps that are not
     stacked: forward against torch's grid_sample, and the two backward forms -- global atomics (any index) and the LDS
@@ -1065,6 +1067,10 @@ def test_point_sample_levels_forward_and_both_backwards(ops, NL, N, M, H, W, P):
     maps = [torch.randn(N, H, W, generator=g) for _ in range(NL)]
     pts = torch.rand(NL, M, P, 2, generator=g) * 1.1 - 0.05  # some points outside [0, 1]
     pts[:, :, :8, 1] = torch.tensor([63.5, 64.0, 64.49, 64.5, 127.5, 128.0, 0.0, H - 0.01]) / H  # band seams and borders
+    if P >= 4096:  # the forward band form's seam: top-corner rows (H + 1) // 2 - 1 and (H + 1) // 2, and the rows just outside the image
+        hb = (H + 1) // 2
+        pts[:, :, 8:14, 1] = torch.tensor([hb - 0.75, hb - 0.5, hb + 0.25, hb + 0.5, 0.25, H - 0.25]) / H
+        pts[:, :, 14:18, 0] = torch.tensor([0.25, W - 0.25, -0.3, W + 0.3]) / W
     index = torch.stack([torch.randperm(N, generator=g)[:M] for _ in range(NL)]).to(torch.int32)
     go = torch.randn(NL, M, P, generator=g)
     refs, ref_grads = [], []

@@ -55,6 +55,54 @@ __global__ __launch_bounds__(256) void point_sample_levels_fwd_kernel(LevelTable
   out[row * P + p] = neg_abs ? -fabsf(v) : v;
 }
 
+// Band form of the forward for many points per map (the uncertainty sampling: 37 632 random points on each matched 256 x 256 map).
+// The gather form reads 4 scattered floats per point -- 64 different 128-byte lines per wave instruction, 32 x the bytes it uses
+// (2 ms per config-2 step for 1.5 GB of useful floats).  Here a workgroup loads a BAND of rows [y_lo, y_hi] of its map into LDS
+// with coalesced float4 loads (the map moves once), walks ALL the row's points (coalesced float2 loads) and samples those whose
+// top corner row lies in its band from LDS; every point is written by exactly one band (points outside the image by band 0).
+// Same arithmetic in the same order as sample_zeros: identical bits.
+__global__ __launch_bounds__(1024) void point_sample_levels_fwd_band_kernel(LevelTable maps, const float* __restrict__ pts,
+                                                                            const int32_t* __restrict__ index, float* __restrict__ out,
+                                                                            int M, int H, int W, int P, int neg_abs, int band_rows) {
+  extern __shared__ __attribute__((aligned(16))) float band[];  // rows y_lo .. y_hi (inclusive) of the map
+  const int bnd = blockIdx.x, m = blockIdx.y, l = blockIdx.z, tid = threadIdx.x;
+  const int y_lo = bnd * band_rows, y_hi = min(H - 1, y_lo + band_rows);  // one row beyond the band's last top-corner row
+  const int n_px = (y_hi - y_lo + 1) * W;
+  const int64_t row = (int64_t)l * M + m;
+  const float* src = maps.p[l] + (int64_t)index[row] * H * W + (int64_t)y_lo * W;
+  if ((n_px & 3) == 0 && (W & 3) == 0) {
+    for (int i = tid; i < n_px / 4; i += 1024) reinterpret_cast<float4*>(band)[i] = reinterpret_cast<const float4*>(src)[i];
+  } else {
+    for (int i = tid; i < n_px; i += 1024) band[i] = src[i];
+  }
+  __syncthreads();
+  const float2* pp = reinterpret_cast<const float2*>(pts) + row * P;
+  float* op = out + row * P;
+  const int own_hi = min(H, y_lo + band_rows);  // this band owns top-corner rows [y_lo, own_hi) -- band 0 also row -1
+  for (int p = tid; p < P; p += 1024) {
+    const float2 pt = pp[p];
+    const float gx = 2.f * pt.x - 1.f, gy = 2.f * pt.y - 1.f;
+    const float x = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    const float y = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    if (!(x > -1.f && x < (float)W && y > -1.f && y < (float)H)) {
+      if (bnd == 0) op[p] = 0.f;  // (neg_abs of 0 is 0)
+      continue;
+    }
+    const float x0f = floorf(x), y0f = floorf(y);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    if (!((y0 >= y_lo && y0 < own_hi) || (bnd == 0 && y0 < 0))) continue;
+    const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+    const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
+    const float* q = band + (y0 - y_lo) * W + x0;
+    float r = 0.f;
+    if (yt && xl) r += q[0] * (fx0 * fy0);
+    if (yt && xr) r += q[1] * (fx1 * fy0);
+    if (yb && xl) r += q[W] * (fx0 * fy1);
+    if (yb && xr) r += q[W + 1] * (fx1 * fy1);
+    op[p] = neg_abs ? -fabsf(r) : r;
+  }
+}
+
 __global__ __launch_bounds__(256) void point_sample_levels_bwd_kernel(const float* __restrict__ grad_out,
                                                                       const float* __restrict__ pts,
                                                                       const int32_t* __restrict__ index, LevelTableMut grads,
@@ -194,8 +242,24 @@ extern "C" int wm2f_point_sample_levels_fwd(const void* const* level_maps, int n
   LevelTable tab;
   for (int l = 0; l < kMaxLossLevels; ++l) tab.p[l] = (const float*)level_maps[l < n_levels ? l : 0];
   for (int l = 0; l < n_levels; ++l) WM2F_REQUIRE(tab.p[l], "%s: null level pointer", who);
-  hipLaunchKernelGGL(point_sample_levels_fwd_kernel, dim3(ceil_div(P, 256), M, n_levels), dim3(256), 0, (hipStream_t)stream,
-                     tab, (const float*)pts, index, (float*)out, M, H, W, P, neg_abs);
+  // many points per map and a map of at most two LDS bands: the band form (the map moves once, the points twice)
+  const int band_rows = (H + 1) / 2;
+  const size_t band_bytes = (size_t)(band_rows + 1) * W * sizeof(float);
+  if (P >= 4096 && band_bytes <= 150 * 1024 && H >= 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)point_sample_levels_fwd_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        set_error("%s: cannot reserve LDS for the band form", who);
+        return WM2F_ELAUNCH;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(point_sample_levels_fwd_band_kernel, dim3(ceil_div(H, band_rows), M, n_levels), dim3(1024), band_bytes,
+                       (hipStream_t)stream, tab, (const float*)pts, index, (float*)out, M, H, W, P, neg_abs, band_rows);
+  } else {
+    hipLaunchKernelGGL(point_sample_levels_fwd_kernel, dim3(ceil_div(P, 256), M, n_levels), dim3(256), 0, (hipStream_t)stream,
+                       tab, (const float*)pts, index, (float*)out, M, H, W, P, neg_abs);
+  }
   WM2F_CHECK_LAUNCH(who);
   return WM2F_OK;
 }
