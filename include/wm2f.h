@@ -17,7 +17,8 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no hidden syncs;
  *   - return 0 on success, a negative WM2F_E* code otherwise; wm2f_last_error() gives the
  *     thread-local message of the last failing call on this thread;
- *   - dtype: WM2F_F32 = 0 (fp32 storage + fp32 arithmetic). WM2F_BF16 = 1 is reserved.
+ *   - dtype: WM2F_F32 = 0 (fp32 storage + fp32 arithmetic); WM2F_BF16 = 1 where an entry point says so (bf16 storage of the
+ *     named tensors, fp32 arithmetic).
  */
 #ifndef WM2F_H
 #define WM2F_H
@@ -76,6 +77,25 @@ int wm2f_msdeform_bwd_det(const void* value, const void* loc, const void* attn_w
                           void* grad_value, void* grad_loc, void* grad_attn_w, void* workspace,
                           const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
                           void* stream);
+
+/* K1 for TRAINING on the merged projection's rows (replaces, as one differentiable op of (value, rows), the prologue of
+ * transformers modeling_mask2former.py:983-1002 -- offsets / (W, H) + reference points, softmax over the L * P logits -- the
+ * core :798-837 and the autograd of both):
+ *   value      (B, S, heads, 32)       fp32 (the arithmetic is fp32, as the dependency's grid_sample is under autocast)
+ *   rows       (B, Q, heads * L*P*3)   [offsets (heads, L, P, 2) in pixels | logits (heads, L*P)] per token, as
+ *                                      cat(sampling_offsets, attention_weights) writes them
+ *   out        (B, Q, heads * 32)
+ *   grad_out   as out;  grad_rows as rows (every element written);  grad_value as value, ZEROED by the caller
+ * dtype = WM2F_F32: rows, out, grad_out, grad_rows are fp32; WM2F_BF16: all four are bf16 (what a bf16-autocast Linear writes
+ * and reads; bf16 -> fp32 is exact, the outputs are rounded to nearest even once).  Reference points are the tokens' pixel
+ * centres (:1127-1156 with valid ratios of 1).  Forward: the streaming kernel (3 levels 1 : 2 : 4 coarse first or a pyramid
+ * it takes, P = 4, Q == S); backward: the LDS-window kernels; heads even.  Otherwise WM2F_EUNSUPPORTED (compose the op from
+ * wm2f_msdeform_fwd / _bwd). */
+int wm2f_msdeform_rows_fwd(const void* value, const void* rows, void* out, const int32_t* level_hw, int B, int S, int Q,
+                           int heads, int D, int L, int P, int dtype, void* stream);
+int wm2f_msdeform_rows_bwd(const void* value, const void* rows, const void* grad_out, void* grad_value, void* grad_rows,
+                           const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
+                           void* stream);
 
 /* K1 with the module prologue fused (HF:983-1002): softmax over the L*P logits and
  * loc = ref + offset / (W_l, H_l) are computed in-kernel.

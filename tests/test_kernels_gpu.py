@@ -264,6 +264,104 @@ def test_k1_backward_local_offsets(ops, shapes, B):
     torch.testing.assert_close(l1.grad.cpu(), l0.grad, rtol=1e-3, atol=2e-4)
 
 
+def _rows_case(shapes, B, spread, seed=21):
+    H, L, P, D = 8, 3, 4, 32
+    g = torch.Generator().manual_seed(seed)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, H, D, generator=g)
+    off = torch.randn(B, S, H, L, P, 2, generator=g) * spread
+    off[0, 5, 1, 0, 2] = torch.tensor([-30.0, 25.0])  # far beyond the window margin: the kernels' slow paths
+    off[0, 7, 3, 2, 1] = torch.tensor([1000.0, -1000.0])  # outside every image: no contribution, zero gradient
+    logits = torch.randn(B, S, H, L * P, generator=g) * 2
+    go = torch.randn(B, S, H * D, generator=g)
+    return value, off, logits, go
+
+
+def _rows_oracle(value, rows, shapes, go, H=8, L=3, P=4):
+    """The composition of HF:983-1002 + :798-837 on the oracle, with autograd: gradients w.r.t. value and the rows."""
+    B, S = rows.shape[:2]
+    v0, r0 = value.clone().requires_grad_(), rows.clone().requires_grad_()
+    n_off = H * L * P * 2
+    off = r0[..., :n_off].view(B, S, H, L, P, 2)
+    ref_pts = O.reference_points(shapes, 1)[0].contiguous()
+    norm = torch.tensor([[ww, hh] for hh, ww in shapes], dtype=value.dtype)
+    loc = ref_pts[None, :, None, :, None, :].to(value.dtype) + off / norm[None, None, None, :, None, :]
+    aw = torch.softmax(r0[..., n_off:].view(B, S, H, L * P), -1).view(B, S, H, L, P)
+    out = O.msdeform_attn_core(v0, shapes, loc, aw)
+    out.backward(go)
+    return out.detach(), v0.grad, r0.grad
+
+
+@pytest.mark.parametrize("shapes,B,spread", [([(8, 8), (16, 16), (32, 32)], 2, 2.0), ([(5, 7), (10, 14), (20, 28)], 3, 2.0),
+                                             ([(2, 3), (4, 6), (8, 12)], 1, 1.0), ([(12, 20), (24, 40), (48, 80)], 2, 3.0)])
+def test_k1_rows_training_op_fp32(ops, shapes, B, spread):
+    """wm2f_msdeform_rows_fwd / _bwd: K1 on the merged projection's [offsets | logits] rows with the prologue inside, forward
+    and backward, against the oracle's autograd of the same composition in float64."""
+    H = 8
+    value, off, logits, go = _rows_case(shapes, B, spread)
+    S = value.shape[1]
+    rows = torch.cat([off.reshape(B, S, -1), logits.reshape(B, S, -1)], -1).contiguous()
+    out0, gv0, gr0 = _rows_oracle(value.double(), rows.double(), shapes, go.double())
+    v1, r1 = dev(value).requires_grad_(), dev(rows).requires_grad_()
+    assert ops.k1_rows_applies(v1, r1, shapes, H)
+    out = ops.ms_deform_attn_rows(v1, shapes, r1, H)
+    out.backward(dev(go))
+    torch.testing.assert_close(out.detach().cpu().double(), out0, rtol=1e-4, atol=5e-5)
+    torch.testing.assert_close(v1.grad.cpu().double(), gv0, rtol=1e-4, atol=3e-5)
+    n_off = H * 3 * 4 * 2
+    # offsets: the gradient is piecewise constant in the fractional position; logits: through the softmax
+    # (a sampling pixel within an fp32 ulp of an integer lands in the neighbouring cell in float64: that point's offset gradient is
+    # the other side of the kink -- a handful of the 10^5..10^6 points, not a tolerance)
+    def close_but(a, b_, rtol, atol, max_bad):
+        bad = (a - b_).abs() > atol + rtol * b_.abs()
+        assert int(bad.sum()) <= max_bad, (int(bad.sum()), float((a - b_).abs().max()))
+    close_but(r1.grad[..., :n_off].cpu().double(), gr0[..., :n_off], 1e-3, 2e-4, 4)
+    torch.testing.assert_close(r1.grad[..., n_off:].cpu().double(), gr0[..., n_off:], rtol=1e-3, atol=1e-4)
+    assert float(r1.grad.view(B, S, -1)[0, 7, 3 * 24 + (2 * 4 + 1) * 2]) == 0.0  # the point outside every image
+    # the same numbers through the unfused composition on the device (ops.ms_deform_attn + torch's prologue): same kernels
+    # underneath, so the two agree far inside the oracle tolerance
+    v2, r2 = dev(value).requires_grad_(), dev(rows).requires_grad_()
+    ref_pts = dev(O.reference_points(shapes, 1)[0].contiguous())
+    norm = dev(torch.tensor([[ww, hh] for hh, ww in shapes], dtype=torch.float32))
+    loc = ref_pts[None, :, None, :, None, :] + r2[..., :n_off].view(B, S, H, 3, 4, 2) / norm[None, None, None, :, None, :]
+    aw = torch.softmax(r2[..., n_off:].view(B, S, H, 12), -1).view(B, S, H, 3, 4)
+    out2 = ops.ms_deform_attn(v2, shapes, loc, aw)
+    out2.backward(dev(go))
+    # (the composition rounds offsets / (W, H) and multiplies back: sampling pixels differ by an ulp or two of the coordinate)
+    torch.testing.assert_close(out.detach(), out2.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(v1.grad, v2.grad, rtol=1e-4, atol=1e-4)
+    close_but(r1.grad.cpu(), r2.grad.cpu(), 1e-3, 3e-4, 8)
+
+
+@pytest.mark.parametrize("shapes,B", [([(8, 8), (16, 16), (32, 32)], 2), ([(5, 7), (10, 14), (20, 28)], 3)])
+def test_k1_rows_training_op_bf16(ops, shapes, B):
+    """The bf16 form (rows, out, grad_out, grad_rows bf16; value cast to fp32 once): on bf16-representable inputs it is the fp32
+    form's arithmetic with ONE rounding of each output to bf16."""
+    H = 8
+    value, off, logits, go = _rows_case(shapes, B, 2.0, seed=22)
+    S = value.shape[1]
+    bf = lambda t: t.to(torch.bfloat16)
+    rows = bf(torch.cat([off.reshape(B, S, -1), logits.reshape(B, S, -1)], -1)).contiguous()
+    value, go = bf(value), bf(go)
+    v1, r1 = dev(value.float()).requires_grad_(), dev(rows.float()).requires_grad_()
+    out1 = ops.ms_deform_attn_rows(v1, shapes, r1, H)
+    out1.backward(dev(go.float()))
+    v2, r2 = dev(value).requires_grad_(), dev(rows).requires_grad_()
+    assert ops.k1_rows_applies(v2, r2, shapes, H)
+    out2 = ops.ms_deform_attn_rows(v2, shapes, r2, H)
+    assert out2.dtype == torch.bfloat16
+    out2.backward(dev(go))
+    assert v2.grad.dtype == torch.bfloat16 and r2.grad.dtype == torch.bfloat16
+    assert torch.equal(out2.detach(), out1.detach().to(torch.bfloat16))  # same arithmetic, one rounding
+    # grad_value: the fp32 sums differ only by the order of the atomics; then one rounding
+    torch.testing.assert_close(v2.grad.float(), v1.grad, rtol=1e-2, atol=1e-2 * float(v1.grad.abs().max()) / 16)
+    assert torch.equal(r2.grad, r1.grad.to(torch.bfloat16))
+    # under torch.autocast the module route hands bf16 rows to the same op
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out3 = ops.ms_deform_attn_rows(dev(value), shapes, dev(rows), H)
+    assert torch.equal(out3, out2.detach())
+
+
 @pytest.mark.parametrize("shapes,B,scale", [([(8, 8), (16, 16), (32, 32)], 2, 1.0), ([(5, 7), (10, 14), (20, 28)], 1, 1e-6),
                                             ([(12, 20), (24, 40)], 2, 3e4)])
 def test_k1_backward_deterministic_form(ops, shapes, B, scale):

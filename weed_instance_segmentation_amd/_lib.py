@@ -29,6 +29,8 @@ SIGNATURES = {
     "wm2f_last_error": (c_char_p, []),
     "wm2f_msdeform_fwd": (c_int, [_P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_msdeform_rows_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_msdeform_rows_bwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_bwd_det_workspace": (c_int64, [_HOST_I32, _I, _I, _I, _I, _I]),
     "wm2f_msdeform_bwd_det": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_fwd": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -257,7 +257,7 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
 // msdeform_tiled_bwd.hip
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
                      void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
-                     int margin, void* stream, const char* who, bool* handled, void* det_ws);
+                     int margin, void* stream, const char* who, bool* handled, void* det_ws, int rows = 0);
 int64_t tiled_bwd_det_workspace(const int32_t* level_hw, int B, int S, int heads, int L);
 
 struct LaunchGeom {
@@ -441,6 +441,59 @@ extern "C" int wm2f_msdeform_fused_lanes_fwd(const void* value, const void* lane
   if (!handled) {
     set_error("%s: the lane-major form exists for the streaming kernel only (D = 32, P = 4, Q == S, 3 levels with sides "
               "1:2:4 coarse first): use wm2f_msdeform_fused_packed_fwd with the [offsets | logits] rows", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  return WM2F_OK;
+}
+
+// K1 for training, on the merged projection's rows: forward and backward of
+//     out = multi_scale_deformable_attention(value, shapes, ref + offsets / (W, H), softmax(logits))        HF:983-1002, :798-837
+// as ONE op of (value, rows), rows = (B, Q, heads * L * P * 3) = [offsets | logits] per token, so that the prologue's
+// elementwise passes (divide, add, softmax, casts) and their backward (and autograd's zero-fill + add of the two row slices)
+// do not exist.  dtype = WM2F_F32: rows, out, grad_out, grad_rows fp32; WM2F_BF16: all four bf16 (what a bf16-autocast Linear
+// writes and reads).  value and grad_value are fp32 either way (the arithmetic is fp32, as the dependency's is under autocast:
+// grid_sample is on its fp32 list).  Reference points are those of HF:1127-1156 with valid ratios of 1 (pixel centres).
+// WM2F_EUNSUPPORTED where the streaming / LDS-window kernels do not apply: the caller composes the op from wm2f_msdeform_fwd.
+extern "C" int wm2f_msdeform_rows_fwd(const void* value, const void* rows, void* out, const int32_t* level_hw, int B, int S, int Q,
+                                      int heads, int D, int L, int P, int dtype, void* stream) {
+  const char* who = "wm2f_msdeform_rows_fwd";
+  WM2F_REQUIRE(dtype == WM2F_F32 || dtype == WM2F_BF16, "%s: dtype", who);
+  WM2F_REQUIRE(value && rows && out && level_hw, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && S > 0 && Q > 0 && heads > 0 && P > 0, "%s: non-positive size", who);
+  LevelInfo lv;
+  if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  bool handled = false;
+  if (D == 32 && L == 3 && P == 4 && heads % 2 == 0) {
+    const int row = heads * L * P * 3, n_off = heads * L * P * 2;
+    const void* logits = dtype == WM2F_BF16 ? (const void*)((const unsigned short*)rows + n_off) : (const void*)((const float*)rows + n_off);
+    if (int rc = launch_stream<true>(value, rows, logits, out, level_hw, B, S, Q, heads, L, P, stream, who, &handled, 0, row, row,
+                                     dtype == WM2F_BF16 ? 24 : 0))
+      return rc;
+  }
+  if (!handled) {
+    set_error("%s: needs D = 32, P = 4, Q == S, an even head count and 3 levels the streaming kernel takes", who);
+    return WM2F_EUNSUPPORTED;
+  }
+  return WM2F_OK;
+}
+
+// grad_value (fp32, ZEROED by the caller: the tiles add into it), grad_rows (every element written).
+extern "C" int wm2f_msdeform_rows_bwd(const void* value, const void* rows, const void* grad_out, void* grad_value, void* grad_rows,
+                                      const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
+                                      void* stream) {
+  const char* who = "wm2f_msdeform_rows_bwd";
+  WM2F_REQUIRE(dtype == WM2F_F32 || dtype == WM2F_BF16, "%s: dtype", who);
+  WM2F_REQUIRE(value && rows && grad_out && grad_value && grad_rows && level_hw, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && S > 0 && Q > 0 && heads > 0 && P > 0, "%s: non-positive size", who);
+  LevelInfo lv;
+  if (int rc = fill_levels(lv, level_hw, L, S, who)) return rc;
+  bool handled = false;
+  if (D == 32)
+    if (int rc = launch_tiled_bwd(value, rows, nullptr, grad_out, grad_value, grad_rows, nullptr, level_hw, B, S, Q, heads, L, P, 4,
+                                  stream, who, &handled, nullptr, dtype == WM2F_BF16 ? 2 : 1))
+      return rc;
+  if (!handled) {
+    set_error("%s: needs D = 32, P = 4, Q == S, an even head count and 3 levels whose windows fit LDS", who);
     return WM2F_EUNSUPPORTED;
   }
   return WM2F_OK;

@@ -125,6 +125,13 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2q = __attribute__((ext_vector_type(2))) unsigned;
+typedef __bf16 bf16x2q_t __attribute__((ext_vector_type(2)));
+typedef float f32x2c_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {  // v_cvt_pk_bf16_f32
+  const f32x2c_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2q_t));
+}
 using f32x4q = __attribute__((ext_vector_type(4))) float;
 
 struct Acc {
@@ -975,6 +982,11 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
   // once per head.  Bits 8 / 9: non-temporal hint on the operand-row loads / the output stores (streams that must not evict
   // the slab).
   constexpr int kOpAux = (OPT & 256) ? 2 : WM2F_OP_AUX, kStAux = (OPT & 512) ? 2 : WM2F_ST_AUX;
+  // OPT bit 10: the [offsets | logits] rows are bf16 (the merged projection's output under bf16 autocast, read as it is);
+  // bit 11: the output is stored as bf16 (what the output projection reads there).  Training forward (wm2f_msdeform_rows_fwd).
+  constexpr bool kRowsLp = FUSED && (OPT & 1024) != 0, kOutLp = (OPT & 2048) != 0;
+  constexpr int kRowEsz = kRowsLp ? 2 : 4;
+  static_assert(!(kRowsLp && (OPT & 1)), "bf16 rows exist in the token-major [offsets | logits] form only");
   // Lane rows: the 36 floats of a (token, head) record come in 16-byte ALIGNED pieces -- [x0 y0 x1 y1] of lanes 0..3, then
   // [x2 y2 w0 w1] of lanes 0..3, then w2 of lanes 0..3 (include/wm2f.h) -- so that a lane's two dwordx4 loads are 16-byte
   // aligned (nine consecutive floats per lane, a 36-byte lane stride, measured 1 % slower in the model).
@@ -1137,7 +1149,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
     rx = ((float)qx + 0.5f) * iw;
     ry = ((float)qyc + 0.5f) * ih;
   };
-  const int a_row = g.a_qstride * 4, b_row = g.b_qstride * 4;  // bytes per token in the two operand arrays (< 2^24: host)
+  const int a_row = g.a_qstride * kRowEsz, b_row = g.b_qstride * kRowEsz;  // bytes per token in the two operand arrays (< 2^24: host)
   auto fetch = [&](const TileId& t) __attribute__((always_inline)) {
     Ops o;
     o.b = t.b;
@@ -1220,7 +1232,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       }
       o.qrow[t2] = q;
     }
-    const int ah = (o.h * (NL * P * 2) + j * 2) * 4, bh = (o.h * (NL * P) + j) * 4;
+    const int ah = (o.h * (NL * P * 2) + j * 2) * kRowEsz, bh = (o.h * (NL * P) + j) * kRowEsz;
 #pragma unroll
     for (int t2 = 0; t2 < kPasses; ++t2) {
       int q = o.qrow[t2];
@@ -1251,8 +1263,15 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
       } else {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-          o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, kOpAux));
-          o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, kOpAux));
+          if constexpr (kRowsLp) {  // bf16 -> fp32 is a shift: exact
+            const unsigned xy = __builtin_amdgcn_raw_buffer_load_b32(a_rs, a_off + l * (P * 2 * 2), 0, kOpAux);
+            const unsigned lg = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(b_rs, b_off + l * (P * 2), 0, kOpAux);
+            o.lc[t2][l] = make_float2(__uint_as_float(xy << 16), __uint_as_float(xy & 0xffff0000u));
+            o.wt[t2][l] = __uint_as_float(lg << 16);
+          } else {
+            o.lc[t2][l] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, a_off + l * (P * 2 * 4), 0, kOpAux));
+            o.wt[t2][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rs, b_off + l * (P * 4), 0, kOpAux));
+          }
         }
       }
     }
@@ -1368,16 +1387,26 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
         unsigned todo = (unsigned)bcast<0>((int)slow[t]) | ((unsigned)bcast<1>((int)slow[t]) << 3) |
                         ((unsigned)bcast<2>((int)slow[t]) << 6) | ((unsigned)bcast<3>((int)slow[t]) << 9);
         constexpr bool lm = kLanes;  // lane-major rows: point k2 of level l sits at [k2 * 9 + 2 * l], its logit at [k2 * 9 + 6 + l]
-        const float* ap = lm ? a_in + (int64_t)cur.qrow[t] * g.a_qstride + (int64_t)cur.h * g.b_qstride
-                             : a_in + (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
-        const float* bp = lm ? ap : b_in + (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
+        // (element offsets: the rows are fp32, or bf16 in the training form)
+        const int64_t ap_e = lm ? (int64_t)cur.qrow[t] * g.a_qstride + (int64_t)cur.h * g.b_qstride
+                                : (int64_t)cur.qrow[t] * g.a_qstride + cur.h * (NL * P * 2);
+        const int64_t bp_e = lm ? ap_e : (int64_t)cur.qrow[t] * g.b_qstride + cur.h * (NL * P);
+        const float* b_base = lm ? a_in : b_in;
+        auto row_a = [&](int i) __attribute__((always_inline)) {
+          if constexpr (kRowsLp) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a_in)[ap_e + i] << 16);
+          else return a_in[ap_e + i];
+        };
+        auto row_b = [&](int i) __attribute__((always_inline)) {
+          if constexpr (kRowsLp) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(b_base)[bp_e + i] << 16);
+          else return b_base[bp_e + i];
+        };
         // where point k2 of level l keeps its x (y follows) and its logit inside the 36-float record
         auto xy_at = [&](int k2, int l) __attribute__((always_inline)) {
           return kAligned ? (l < 2 ? k2 * 4 + 2 * l : 16 + k2 * 4) : (lm ? k2 * 9 + 2 * l : (l * P + k2) * 2);
         };
         auto logit_at = [&](int i) __attribute__((always_inline)) {  // i = l * P + k2
           const int k2 = i & 3, l = i >> 2;
-          return kAligned ? bp[l < 2 ? 16 + k2 * 4 + 2 + l : 32 + k2] : (lm ? bp[k2 * 9 + 6 + l] : bp[i]);
+          return kAligned ? row_b(l < 2 ? 16 + k2 * 4 + 2 + l : 32 + k2) : (lm ? row_b(k2 * 9 + 6 + l) : row_b(i));
         };
         float refx = 0.f, refy = 0.f, sm_max = 0.f, sm_inv = 1.f;
         if (FUSED && todo) {  // re-derive what the fast path no longer holds in registers
@@ -1394,7 +1423,7 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
           const int k2 = i / 3, l = i - k2 * 3;
           const int Wl = l == 2 ? g.W[2] : (l == 1 ? g.W[1] : g.W[0]), Hl = l == 2 ? g.H[2] : (l == 1 ? g.H[1] : g.H[0]);
           const int st_l = l == 0 ? g.start[0] : (l == 1 ? g.start[1] : g.start[2]);
-          const float lx = ap[xy_at(k2, l)], ly = ap[xy_at(k2, l) + 1];
+          const float lx = row_a(xy_at(k2, l)), ly = row_a(xy_at(k2, l) + 1);
           float aw = logit_at(l * P + k2), x, y;
           if (FUSED) {
             aw = __expf(aw - sm_max) * sm_inv;
@@ -1409,9 +1438,14 @@ __global__ __launch_bounds__(SCfg<CH>::THREADS, CH == 8 ? 1 : 4) void msdeform_s
           if (CH == 8) quad_point_slow(r2, vlev + (off2 >> 2), Hl, Wl, row_stride, x, y, aw);
         }
       }
-      const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * 4) + cur.hh * 64) : kOobOffset;
+      const unsigned o_off = cur.valid[t] ? (unsigned)((cur.qrow[t] * heads + cur.h) * (D * (kOutLp ? 2 : 4)) + cur.hh * (kOutLp ? 32 : 64)) : kOobOffset;
       if (MODE == 6) {  // keep the sums alive without a store
         asm volatile("" ::"v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y), "v"(r2.z), "v"(r2.w));
+        continue;
+      }
+      if constexpr (kOutLp) {  // round to nearest even, as a cast pass over the fp32 output would
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2q){pack_bf16_rne(r1.x, r1.y), pack_bf16_rne(r1.z, r1.w)}, out_rs, (int)(o_off + (off1 >> 1)), 0, kStAux);
+        if (CH == 8) __builtin_amdgcn_raw_buffer_store_b64((u32x2q){pack_bf16_rne(r2.x, r2.y), pack_bf16_rne(r2.z, r2.w)}, out_rs, (int)(o_off + (off2 >> 1)), 0, kStAux);
         continue;
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r1), out_rs, (int)(o_off + off1), 0, kStAux);
@@ -1612,6 +1646,12 @@ int launch_stream(const void* value, const void* a, const void* b, void* out, co
   }
   int threads = SCfg<8>::THREADS;
   if (!exact) kfn = ln ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 1> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 0>;
+  // lanes bits 3 / 4: bf16 [offsets | logits] rows / bf16 output (the training forward under bf16 autocast: both or neither)
+  if constexpr (FUSED) if ((lanes & 24) == 24) {
+    if (ln || slab || mode != 0) return WM2F_OK;
+    kfn = !exact ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, false, 1024 + 2048>
+                 : (all_full ? msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 8 + 1024 + 2048> : msdeform_stream_fwd_kernel<FUSED, 0, 0, 8, true, 1024 + 2048>);
+  } else if (lanes & 24) return WM2F_OK;
 #ifndef WM2F_PROFILING
   if (mode != 0) return WM2F_OK;  // every other mode is a measured negative, an ablation or a stamped build: profiling library
 #else

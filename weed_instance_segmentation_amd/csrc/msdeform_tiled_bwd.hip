@@ -86,6 +86,83 @@ __device__ __forceinline__ int tile_query(const int* lv_tab, int qi, int Q) {
   return q > Q - 1 ? Q - 1 : q;
 }
 
+// the same, plus where the query sits: its level and its (column, row) there (the reference point of the ROWS forms)
+template <int NL>
+__device__ __forceinline__ int tile_query_ex(const int* lv_tab, int qi, int Q, int& Wq, int& Hq, int& qx, int& qy) {
+  int lq = 0;
+#pragma unroll
+  for (int l = 1; l < NL; ++l) lq += (qi >= lv_tab[l * 8 + 6]) ? 1 : 0;
+  const int4 ta = *reinterpret_cast<const int4*>(lv_tab + lq * 8), tb = *reinterpret_cast<const int4*>(lv_tab + lq * 8 + 4);
+  const int loc_i = qi - tb.z;
+  const int ly_ = (int)(((float)loc_i + 0.5f) * __int_as_float(tb.w));
+  const int lx_ = loc_i - ly_ * ta.w;
+  Hq = ta.x;
+  Wq = ta.y;
+  qx = tb.x + lx_;
+  qy = tb.y + ly_;
+  int q = ta.z + qy * ta.y + qx;
+  return q > Q - 1 ? Q - 1 : q;
+}
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+typedef __bf16 bf16x2b_t __attribute__((ext_vector_type(2)));
+typedef float f32x2b_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_b(float lo, float hi) {  // v_cvt_pk_bf16_f32, round to nearest even
+  const f32x2b_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2b_t));
+}
+
+// ROWS forms (wm2f_msdeform_rows_bwd): the kernels read the merged projection's [offsets | logits] rows (B, Q, heads * NL * P * 3)
+// -- fp32 (ROWS = 1) or bf16 (ROWS = 2: grad_out and the row gradients are bf16 as well) -- and redo the prologue of HF:983-1002
+// in registers: softmax over the (query, head)'s NL * P logits, sampling pixel = reference pixel + offset (the reference point
+// of a token is the centre of its own pixel, HF:1127-1156 with valid ratios of 1; in pixels of level l:
+// (column + 0.5) * W_l / W_q - 0.5, exact for the 1 : 2 : 4 pyramids).  The 12 logits of one (query, head):
+template <int ROWS, int NP>
+__device__ __forceinline__ void load_logits(const void* rows, int64_t elem, float (&lg)[NP]) {
+  static_assert(NP % 4 == 0, "whole 4-element pieces");
+  if (ROWS == 2) {
+    const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(rows) + elem);
+#pragma unroll
+    for (int i = 0; i < NP / 4; ++i) {
+      const uint2 u = p[i];
+      lg[4 * i] = bf_lo(u.x); lg[4 * i + 1] = bf_hi(u.x); lg[4 * i + 2] = bf_lo(u.y); lg[4 * i + 3] = bf_hi(u.y);
+    }
+  } else {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rows) + elem);
+#pragma unroll
+    for (int i = 0; i < NP / 4; ++i) {
+      const float4 u = p[i];
+      lg[4 * i] = u.x; lg[4 * i + 1] = u.y; lg[4 * i + 2] = u.z; lg[4 * i + 3] = u.w;
+    }
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ void softmax_regs(float (&lg)[NP]) {  // in place; HF:986-991
+  float mx = lg[0];
+#pragma unroll
+  for (int i = 1; i < NP; ++i) mx = fmaxf(mx, lg[i]);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    lg[i] = __expf(lg[i] - mx);
+    s += lg[i];
+  }
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) lg[i] *= inv;
+}
+
+template <int ROWS>
+__device__ __forceinline__ float2 load_offset(const void* rows, int64_t elem) {  // (x, y) of one point; elem even
+  if (ROWS == 2) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(rows) + elem);
+    return make_float2(bf_lo(u), bf_hi(u));
+  }
+  return *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(rows) + elem);
+}
+
 __device__ __forceinline__ float dot8(const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
   return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
 }
@@ -102,7 +179,7 @@ __device__ __forceinline__ void pixel_coords(float lx, float ly, int Wl, int Hl,
 }
 
 // ---------------------------------------------------------------------------------- kernel A
-template <int NL, int P>
+template <int NL, int P, int ROWS = 0>
 __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn_w,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, TileGeom g, int S,
@@ -139,24 +216,52 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
   __syncthreads();
 
   for (int qi = slot; qi < c.nq; qi += kSlots) {
-    const int q = tile_query<NL>(lv_tab, qi, Q);
+    int Wq = 1, Hq = 1, qx = 0, qy = 0;
+    const int q = ROWS ? tile_query_ex<NL>(lv_tab, qi, Q, Wq, Hq, qx, qy) : tile_query<NL>(lv_tab, qi, Q);
     const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
     const float* lp = loc + pair * (NL * P * 2);
     const float* wp = attn_w + pair * (NL * P);
-    const float4 go0 = ld4g(grad_out + pair * D + j * 4), go1 = ld4g(grad_out + pair * D + 16 + j * 4);
+    float4 go0, go1;
+    if (ROWS == 2) {
+      const unsigned short* gp = reinterpret_cast<const unsigned short*>(grad_out) + pair * D + j * 4;
+      const uint2 a = *reinterpret_cast<const uint2*>(gp), b2 = *reinterpret_cast<const uint2*>(gp + 16);
+      go0 = make_float4(bf_lo(a.x), bf_hi(a.x), bf_lo(a.y), bf_hi(a.y));
+      go1 = make_float4(bf_lo(b2.x), bf_hi(b2.x), bf_lo(b2.y), bf_hi(b2.y));
+    } else {
+      go0 = ld4g(grad_out + pair * D + j * 4);
+      go1 = ld4g(grad_out + pair * D + 16 + j * 4);
+    }
+    // ROWS: this (query, head)'s piece of the token's row: offsets at off_e, logits at log_e (element indices)
+    const int64_t row_e = ((int64_t)c.b * Q + q) * (heads * NL * P * 3);
+    const int64_t off_e = row_e + c.h * (NL * P * 2), log_e = row_e + heads * (NL * P * 2) + c.h * (NL * P);
+    float awr[NL * P];
+    if (ROWS) {
+      load_logits<ROWS, NL * P>(loc, log_e, awr);
+      softmax_regs<NL * P>(awr);
+    }
+    float gwa[NL * P], gxa[NL * P], gya[NL * P];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l], wh = g.win_h[l];
       const float4* wl = win + g.lds_off4[l] + j;
       const float* vlev = vb + (int64_t)g.start[l] * row_stride + j * 4;
-      const float4 aw4 = ld4g(wp + l * P);
-      float gw[P], gx[P], gy[P];
+      float4 aw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!ROWS) aw4 = ld4g(wp + l * P);
+      // ROWS: the query's reference pixel at this level, see above
+      const float rpx = ((float)qx + 0.5f) * ((float)Wl / (float)Wq) - 0.5f, rpy = ((float)qy + 0.5f) * ((float)Hl / (float)Hq) - 0.5f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
-        const float aw = p == 0 ? aw4.x : p == 1 ? aw4.y : p == 2 ? aw4.z : aw4.w;
-        float x, y;
-        pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
+        float aw, x, y;
+        if (ROWS) {
+          const float2 of = load_offset<ROWS>(loc, off_e + (l * P + p) * 2);
+          aw = awr[l * P + p];
+          x = rpx + of.x;
+          y = rpy + of.y;
+        } else {
+          const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
+          aw = p == 0 ? aw4.x : p == 1 ? aw4.y : p == 2 ? aw4.z : aw4.w;
+          pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
+        }
         const float x0f = floorf(x), y0f = floorf(y);
         const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
         const int xr = (int)x0f - c.wx0[l], yr = (int)y0f - c.wy0[l];
@@ -182,14 +287,39 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
         d10 = quad_sum(d10);
         d11 = quad_sum(d11);
         const bool inside = x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl;
-        gw[p] = inside ? fy0 * (fx0 * d00 + fx1 * d01) + fy1 * (fx0 * d10 + fx1 * d11) : 0.f;
-        gx[p] = inside ? aw * (float)Wl * (fy0 * (d01 - d00) + fy1 * (d11 - d10)) : 0.f;
-        gy[p] = inside ? aw * (float)Hl * (fx0 * (d10 - d00) + fx1 * (d11 - d01)) : 0.f;
+        // d pixel / d location = (W_l, H_l); d pixel / d offset = 1 (ROWS)
+        const float sx = ROWS ? aw : aw * (float)Wl, sy = ROWS ? aw : aw * (float)Hl;
+        gwa[l * P + p] = inside ? fy0 * (fx0 * d00 + fx1 * d01) + fy1 * (fx0 * d10 + fx1 * d11) : 0.f;
+        gxa[l * P + p] = inside ? sx * (fy0 * (d01 - d00) + fy1 * (d11 - d10)) : 0.f;
+        gya[l * P + p] = inside ? sy * (fx0 * (d10 - d00) + fx1 * (d11 - d01)) : 0.f;
       }
-      if (j == 0) {
-        *reinterpret_cast<float4*>(grad_w + pair * (NL * P) + l * P) = make_float4(gw[0], gw[1], gw[2], gw[3]);
-        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2) = make_float4(gx[0], gy[0], gx[1], gy[1]);
-        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2 + 4) = make_float4(gx[2], gy[2], gx[3], gy[3]);
+      if (!ROWS && j == 0) {
+        *reinterpret_cast<float4*>(grad_w + pair * (NL * P) + l * P) = make_float4(gwa[l * P], gwa[l * P + 1], gwa[l * P + 2], gwa[l * P + 3]);
+        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2) = make_float4(gxa[l * P], gya[l * P], gxa[l * P + 1], gya[l * P + 1]);
+        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2 + 4) = make_float4(gxa[l * P + 2], gya[l * P + 2], gxa[l * P + 3], gya[l * P + 3]);
+      }
+    }
+    if (ROWS) {
+      // softmax backward: d logit_i = w_i (g_i - sum_k w_k g_k); then lane l of the quad stores level l's 8 offset and 4 logit gradients
+      float sdot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL * P; ++i) sdot += awr[i] * gwa[i];
+#pragma unroll
+      for (int i = 0; i < NL * P; ++i) gwa[i] = awr[i] * (gwa[i] - sdot);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        if (j != (l & 3)) continue;
+        const int i0 = l * P;
+        if (ROWS == 2) {
+          unsigned short* gr = reinterpret_cast<unsigned short*>(grad_loc);
+          *reinterpret_cast<uint4*>(gr + off_e + i0 * 2) = make_uint4(pack_bf16_b(gxa[i0], gya[i0]), pack_bf16_b(gxa[i0 + 1], gya[i0 + 1]),
+                                                                       pack_bf16_b(gxa[i0 + 2], gya[i0 + 2]), pack_bf16_b(gxa[i0 + 3], gya[i0 + 3]));
+          *reinterpret_cast<uint2*>(gr + log_e + i0) = make_uint2(pack_bf16_b(gwa[i0], gwa[i0 + 1]), pack_bf16_b(gwa[i0 + 2], gwa[i0 + 3]));
+        } else {
+          *reinterpret_cast<float4*>(grad_loc + off_e + i0 * 2) = make_float4(gxa[i0], gya[i0], gxa[i0 + 1], gya[i0 + 1]);
+          *reinterpret_cast<float4*>(grad_loc + off_e + i0 * 2 + 4) = make_float4(gxa[i0 + 2], gya[i0 + 2], gxa[i0 + 3], gya[i0 + 3]);
+          *reinterpret_cast<float4*>(grad_loc + log_e + i0) = make_float4(gwa[i0], gwa[i0 + 1], gwa[i0 + 2], gwa[i0 + 3]);
+        }
       }
     }
   }
@@ -377,7 +507,7 @@ typedef __attribute__((address_space(3))) int lds_int_t;
 // flush and the slab store undo it.
 // NT threads (16 waves: 4 per SIMD, so that one wave's vector work runs under another's LDS atomics), and a pass's 12
 // points split over NSPLIT waves (21 passes per tile do not divide over 16 waves; 42 half-passes nearly do).
-template <int NL, int P, bool DET, int NT = kQuadBwdThreads, int NSPLIT = 2>
+template <int NL, int P, bool DET, int NT = kQuadBwdThreads, int NSPLIT = 2, int ROWS = 0>
 __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn_w, const float* __restrict__ grad_out,
     float* __restrict__ grad_value, float* __restrict__ staging, long long* __restrict__ acc64, const int* __restrict__ emax_bits,
@@ -394,6 +524,11 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
   float* gvb = grad_value + ((int64_t)c.b * S * heads + c.h) * D;
 
   for (int i = tid; i < g.lv_tab_off4; i += NT) win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // grad_out element (ROWS = 2: bf16)
+  auto go_at = [&](int64_t i) __attribute__((always_inline)) {
+    if (ROWS == 2) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(grad_out)[i] << 16);
+    return grad_out[i];
+  };
   // per-channel scale of the fixed-point sums: as in the kernel above (2^22 / max |grad_out| of this tile, head, channel)
   __shared__ float ch_max[NT / kWave][32];
   __shared__ float ch_scale[32], ch_inv[32];
@@ -402,7 +537,7 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
     float m = 0.f;
     for (int qi = wave * 2 + (lane >> 5); qi < c.nq; qi += 2 * kWaves) {
       const int q = tile_query<NL>(lv_tab, qi, Q);
-      m = fmaxf(m, fabsf(grad_out[(((int64_t)c.b * Q + q) * heads + c.h) * D + ch]));
+      m = fmaxf(m, fabsf(go_at((((int64_t)c.b * Q + q) * heads + c.h) * D + ch)));
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if (lane < 32) ch_max[wave][lane] = m;
@@ -435,27 +570,44 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
     const int pass = unit / NSPLIT, part_pts = unit - pass * NSPLIT;
     const int qi = pass * 16 + slot;
     const bool valid = qi < c.nq;
-    const int q = tile_query<NL>(lv_tab, valid ? qi : c.nq - 1, Q);
+    int Wq = 1, Hq = 1, qx = 0, qy = 0;
+    const int q = ROWS ? tile_query_ex<NL>(lv_tab, valid ? qi : c.nq - 1, Q, Wq, Hq, qx, qy) : tile_query<NL>(lv_tab, valid ? qi : c.nq - 1, Q);
     const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
     float raw[8], gs[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      raw[k] = valid ? grad_out[pair * D + 4 * k + j] : 0.f;
+      raw[k] = valid ? go_at(pair * D + 4 * k + j) : 0.f;
       gs[k] = raw[k] * sc[k];
     }
     const float* lp = loc + pair * (NP * 2);
     const float* ap = attn_w + pair * NP;
+    // ROWS: softmax over the (query, head)'s logits and the reference pixel, redone here (see load_logits)
+    const int64_t row_e = ((int64_t)c.b * Q + q) * (heads * NP * 3);
+    const int64_t off_e = row_e + c.h * (NP * 2), log_e = row_e + heads * (NP * 2) + c.h * NP;
+    float awr[NP];
+    if (ROWS) {
+      load_logits<ROWS, NP>(loc, log_e, awr);
+      softmax_regs<NP>(awr);
+    }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l], wh = g.win_h[l];
       const int base = g.lds_off4[l] * 4 + j;
+      const float rpx = ((float)qx + 0.5f) * ((float)Wl / (float)Wq) - 0.5f, rpy = ((float)qy + 0.5f) * ((float)Hl / (float)Hq) - 0.5f;
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         if (NSPLIT > 1 && (l * P + p) % NSPLIT != part_pts) continue;  // wave-uniform
-        const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
-        const float aw = valid ? ap[l * P + p] : 0.f;
-        float x, y;
-        pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
+        float aw, x, y;
+        if (ROWS) {
+          const float2 of = load_offset<ROWS>(loc, off_e + (l * P + p) * 2);
+          aw = valid ? awr[l * P + p] : 0.f;
+          x = rpx + of.x;
+          y = rpy + of.y;
+        } else {
+          const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
+          aw = valid ? ap[l * P + p] : 0.f;
+          pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
+        }
         if (!(x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl) || aw == 0.f) continue;  // per lane (quad-uniform)
         const float x0f = floorf(x), y0f = floorf(y);
         const int x0 = (int)x0f, y0 = (int)y0f;
@@ -632,9 +784,12 @@ int64_t tiled_bwd_det_workspace(const int32_t* level_hw, int B, int S, int heads
 
 int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, const void* grad_out, void* grad_value,
                      void* grad_loc, void* grad_w, const int32_t* level_hw, int B, int S, int Q, int heads, int L, int P,
-                     int margin, void* stream, const char* who, bool* handled, void* det_ws) {
+                     int margin, void* stream, const char* who, bool* handled, void* det_ws, int rows) {
+  // rows: 0 = loc / attn_w operands; 1 / 2 = the ROWS forms (fp32 / bf16 [offsets | logits] rows in `loc`, their gradient in
+  // `grad_loc`; attn_w and grad_w unused): 3 levels, an even head count (16-byte row pieces), no deterministic form
   *handled = false;
   if (P != 4 || L < 1 || L > kMaxLv || margin < 0 || (int64_t)Q != S) return WM2F_OK;
+  if (rows && (L != 3 || det_ws || (heads & 1) || rows > 2)) return WM2F_OK;
   TiledPlan p = plan_tiled(level_hw, L, margin);
   if (!p.ok) return WM2F_OK;
   p.g.order = 1;
@@ -675,6 +830,31 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
       reach = reach > r2 ? reach : r2;
     }
     if ((2 * reach + 1) * (2 * reach + 1) > 64 || heads * 32 < 64) return WM2F_OK;  // the gather tests its candidates one per lane
+  }
+  if (rows) {
+    auto ka = rows == 2 ? msdeform_tiled_bwd_lw_kernel<3, 4, 2> : msdeform_tiled_bwd_lw_kernel<3, 4, 1>;
+    auto kb = rows == 2 ? msdeform_tiled_bwd_value_quad_kernel<3, 4, false, kQuadBwdThreads, 2, 2>
+                        : msdeform_tiled_bwd_value_quad_kernel<3, 4, false, kQuadBwdThreads, 2, 1>;
+    if (p.lds_bytes > 64 * 1024) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+      hipError_t e2 = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        set_error("%s: cannot raise dynamic LDS to %zu", who, p.lds_bytes);
+        return WM2F_ELAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(ka, dim3(per_xcd * kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)value, (const float*)loc,
+                       (const float*)nullptr, (const float*)grad_out, (float*)grad_loc, (float*)nullptr, p.g, S, Q, heads, (int)n_logical, per_xcd);
+    hipLaunchKernelGGL(kb, dim3(per_xcd * kNumXcd), dim3(kQuadBwdThreads), p.lds_bytes, st, (const float*)loc, (const float*)nullptr,
+                       (const float*)grad_out, (float*)grad_value, (float*)nullptr, (long long*)nullptr, (const int*)nullptr, p.g, S, Q, heads,
+                       (int)n_logical, per_xcd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("%s: tiled backward launch failed: %s", who, hipGetErrorString(e));
+      return WM2F_ELAUNCH;
+    }
+    *handled = true;
+    return WM2F_OK;
   }
 #define WM2F_TB(NLv)                                                                                              \
   case NLv: {                                                                                                     \

@@ -140,6 +140,11 @@ class MSDeformAttn(nn.Module):
             # instead of two); the concatenation is tracked by autograd, so each Linear's parameters get their rows of dW
             so, aw_ = self.sampling_offsets, self.attention_weights
             ol = lin(hp, torch.cat([so.weight, aw_.weight], 0), torch.cat([so.bias, aw_.bias], 0))
+            if ops.k1_rows_applies(value, ol, level_hw, H, P):
+                # the encoder's own shape: K1 on the rows themselves -- softmax, location arithmetic and their backward inside the
+                # kernels (ops.ms_deform_attn_rows; `ref` is the pixel-centre grid of reference_points(), which they rebuild)
+                out = ops.ms_deform_attn_rows(value, level_hw, ol, H)
+                return lin(out, self.output_proj.weight, self.output_proj.bias)
             n_off = H * L * P * 2
             off = ol[..., :n_off].view(B, S, H, L, P, 2)
             logits = ol[..., n_off:].view(B, S, H, L * P)

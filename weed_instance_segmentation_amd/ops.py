@@ -12,7 +12,7 @@ from typing import Sequence
 import torch
 
 from . import _lib
-from ._lib import WM2F_F32, check, host_i32, load
+from ._lib import WM2F_BF16, WM2F_F32, check, host_i32, load
 
 
 class KernelTimer:
@@ -154,6 +154,68 @@ def ms_deform_attn(value: torch.Tensor, level_hw: Sequence[Sequence[int]], loc: 
     """K1 -- multi_scale_deformable_attention (HF:798-837).
     value (B,S,heads,D), loc (B,Q,heads,L,P,2), attn_w (B,Q,heads,L,P) -> (B,Q,heads*D)."""
     return _MSDeformAttn.apply(value, loc, attn_w, level_hw)
+
+
+def k1_rows_applies(value: torch.Tensor, rows: torch.Tensor, level_hw, heads: int, n_points: int = 4) -> bool:
+    """Host-side copy of the shape test of wm2f_msdeform_rows_fwd / _bwd (K1 for training on the merged projection's rows):
+    the streaming kernel's shapes (3 levels 1 : 2 : 4 coarse first, 4 points, head_dim 32, queries == tokens), an even head
+    count, rows fp32 or bf16, and no deterministic-algorithms request (the fixed-point grad_value form takes loc / attn_w)."""
+    if not (value.is_cuda and rows.is_cuda and value.dim() == 4 and rows.dim() == 3) or heads % 2:
+        return False
+    B, S, H, D = value.shape
+    if H != heads or rows.shape != (B, S, heads * 3 * n_points * 3) or rows.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    if value.dtype not in (torch.float32, rows.dtype):
+        return False
+    det = K1_BWD_DETERMINISTIC if K1_BWD_DETERMINISTIC is not None else torch.are_deterministic_algorithms_enabled()
+    return (not det) and k1_lanes_applies(level_hw, S, D, n_points, B, heads)
+
+
+class _MSDeformAttnRows(torch.autograd.Function):
+    """K1 with the prologue of HF:983-1002 inside, differentiable: (value, rows = [offsets | logits]) -> out, with the backward
+    kernels writing the ROW gradient directly (wm2f_msdeform_rows_fwd / _bwd).  rows / out / their gradients share one dtype
+    (fp32, or bf16 under bf16 autocast); value is cast to fp32 once (the kernels' windows are fp32) and kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, value, rows, level_hw, heads):
+        B, S, H, D = value.shape
+        v32 = _req(value if value.dtype == torch.float32 else value.float(), "value")
+        rows = _req(rows, "rows", rows.dtype)
+        lp = rows.dtype == torch.bfloat16
+        out = torch.empty(B, S, H * D, device=value.device, dtype=rows.dtype)
+        lv = host_i32([x for hw in level_hw for x in hw])
+        with torch.cuda.device(value.device):
+            check(_timed("msdeform_rows_fwd", v32, lambda: load().wm2f_msdeform_rows_fwd(
+                _p(v32), _p(rows), _p(out), lv, B, S, S, H, D, 3, 4, WM2F_BF16 if lp else WM2F_F32, _stream(v32))),
+                "wm2f_msdeform_rows_fwd")
+        ctx.save_for_backward(v32, rows)
+        ctx.level_hw = tuple(tuple(int(x) for x in hw) for hw in level_hw)
+        ctx.value_dtype = value.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        v32, rows = ctx.saved_tensors
+        B, S, H, D = v32.shape
+        lp = rows.dtype == torch.bfloat16
+        grad_out = _req(grad_out if grad_out.dtype == rows.dtype else grad_out.to(rows.dtype), "grad_out", rows.dtype)
+        g_value = torch.zeros_like(v32)
+        g_rows = torch.empty_like(rows)
+        lv = host_i32([x for hw in ctx.level_hw for x in hw])
+        with torch.cuda.device(v32.device):
+            check(_timed("msdeform_rows_bwd", v32, lambda: load().wm2f_msdeform_rows_bwd(
+                _p(v32), _p(rows), _p(grad_out), _p(g_value), _p(g_rows), lv, B, S, S, H, D, 3, 4,
+                WM2F_BF16 if lp else WM2F_F32, _stream(v32))), "wm2f_msdeform_rows_bwd")
+        return (g_value if ctx.value_dtype == torch.float32 else g_value.to(ctx.value_dtype)), g_rows, None, None
+
+
+def ms_deform_attn_rows(value: torch.Tensor, level_hw, rows: torch.Tensor, heads: int) -> torch.Tensor:
+    """K1 on the merged projection's rows, with autograd (training): value (B,S,heads,32) fp32 / bf16, rows (B,S,heads*36) =
+    [offsets (heads,3,4,2) | logits (heads,12)] fp32 / bf16 -> (B,S,heads*32) in the rows' dtype.  Reference points are the
+    tokens' pixel centres (HF:1127-1156 with valid ratios of 1).  Check k1_rows_applies first."""
+    if not k1_rows_applies(value, rows, level_hw, heads):
+        raise ValueError("ms_deform_attn_rows: shapes / dtypes outside wm2f_msdeform_rows_fwd (see k1_rows_applies)")
+    return _MSDeformAttnRows.apply(value, rows, level_hw, heads)
 
 
 def ms_deform_attn_fused(value: torch.Tensor, level_hw, offsets: torch.Tensor, logits: torch.Tensor,
