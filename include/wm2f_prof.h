@@ -19,6 +19,9 @@
  *   - wm2f_msdeform_fused_lanes_fwd reads WM2F_K1_MODE on every launch: 200 strip order, 300 round-1 loader schedule, 500
  *     Z-order, 600 / 700 static wave priority, 800 slab order, 801 / 802 / 803 slab order with non-temporal operand loads /
  *     output stores / both, 807 slab order stamped (tools/k1_slab_inmodel.py, tools/k1_stamps.py)
+ *   - wm2f_msdeform_bwd reads WM2F_K1_BWD_OLD (1: the wave-per-query grad_value kernel); wm2f_msdeform_rows_bwd reads
+ *     WM2F_K1_LW_THREADS: 512 / 768 = 8 / 12 waves per workgroup in the row-gradient kernel, 1 / 2 = that kernel without window
+ *     staging / staging only (OUTPUTS NOT VALID), 3 = that kernel alone (grad_value not computed)   (tools/probes/k1_rows_bench.py)
  *   - K2 / K3 read their experiment knobs from the environment on every launch
  *       WM2F_K2_QTILES, WM2F_K2_WG_TARGET, WM2F_K2_FULL, WM2F_K2_QSPLIT, WM2F_K3_DBG   (tools/kbench.py)
  *   - the stamp buffer below: a __device__ global, i.e. the global mutable state the production library forbids.

@@ -23,6 +23,7 @@
 // kernel B 2.31 ms, kernel A 0.51 ms.
 #include "msdeform_tiled.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace wm2f {
 
@@ -149,7 +150,7 @@ __device__ __forceinline__ void softmax_regs(float (&lg)[NP]) {  // in place; HF
     lg[i] = __expf(lg[i] - mx);
     s += lg[i];
   }
-  const float inv = 1.f / s;
+  const float inv = __builtin_amdgcn_rcpf(s);  // as the forward kernel's prologue
 #pragma unroll
   for (int i = 0; i < NP; ++i) lg[i] *= inv;
 }
@@ -167,6 +168,28 @@ __device__ __forceinline__ float dot8(const float4& a0, const float4& a1, const 
   return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
 }
 
+template <int K>
+__device__ __forceinline__ int bcast_dpp(int v) {  // value of lane K of this lane's quad
+  return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float quad_sum_dpp(float v) {  // same order of additions as quad_sum below: (v + xor 1) + xor 2
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+  return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_max_dpp(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)));
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)));
+}
+// dot8 in the packed form the hardware has (v_pk_fma_f32: two products per instruction on register PAIRS as they were loaded):
+// even and odd channels run as two partial sums, added at the end -- 4 packed FMAs + 1 add per corner.  (Left to the compiler,
+// dot8's serial chain was packed ACROSS corners, with two v_mov per v_pk_fma to build the pairs: 112 instructions per point.)
+__device__ __forceinline__ float dot8p(const f32x2 (&g)[4], const float4& a, const float4& b) {
+  f32x2 acc = (f32x2){a.x, a.y} * g[0];
+  acc = __builtin_elementwise_fma((f32x2){a.z, a.w}, g[1], acc);
+  acc = __builtin_elementwise_fma((f32x2){b.x, b.y}, g[2], acc);
+  acc = __builtin_elementwise_fma((f32x2){b.z, b.w}, g[3], acc);
+  return acc.x + acc.y;
+}
 __device__ __forceinline__ float quad_sum(float v) {  // over the 4 lanes of a query
   v += __shfl_xor(v, 1, kWave);
   v += __shfl_xor(v, 2, kWave);
@@ -179,12 +202,13 @@ __device__ __forceinline__ void pixel_coords(float lx, float ly, int Wl, int Hl,
 }
 
 // ---------------------------------------------------------------------------------- kernel A
-template <int NL, int P, int ROWS = 0>
-__global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
+// ABL (profiling build, OUTPUTS NOT VALID): 1 = no window staging, 2 = staging only
+template <int NL, int P, int ROWS = 0, int NT = kBwdThreads, int ABL = 0>
+__global__ __launch_bounds__(NT) void msdeform_tiled_bwd_lw_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn_w,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, TileGeom g, int S,
     int Q, int heads, int n_logical, int per_xcd) {
-  constexpr int D = 32, kLQ = 4, kSlots = kBwdThreads / kLQ, kWaves = kBwdThreads / kWave;
+  constexpr int D = 32, kLQ = 4, kSlots = NT / kLQ, kWaves = NT / kWave;
   extern __shared__ __attribute__((aligned(16))) float4 win[];
   const int id = xcd_contiguous_id(blockIdx.x, per_xcd);
   if (id >= n_logical) return;
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
   // stage the value windows (zero outside the image)
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
+    if (ABL == 1) break;
     const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l];
     const int npix = ww * g.win_h[l], n_chunks = (npix + 7) >> 3;
     const float inv_ww = 1.f / (float)ww;
@@ -214,13 +239,18 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (ABL == 2) return;
 
+  // One quad per (query, head); lane j owns the 8 channels {4 j .. 4 j + 3, 16 + 4 j ..} AND, per level, point j: it works out
+  // that point's pixel, weights and window address once (not four times), the quad then walks the level's four points --
+  // address of point K by DPP broadcast, 8 window reads and 4 eight-channel dot products per lane, DPP sums over the quad,
+  // kept by lane K -- and lane j finishes its own point's three gradients.  (The first form computed every point in all four
+  // lanes and summed through ds_bpermute: ~200 vector instructions per point and lane, 975 of the kernel's 1015 us at
+  // config 2; tools/probes/k1_rows_bench.py with WM2F_K1_LW_THREADS=1 / 2.)
   for (int qi = slot; qi < c.nq; qi += kSlots) {
     int Wq = 1, Hq = 1, qx = 0, qy = 0;
     const int q = ROWS ? tile_query_ex<NL>(lv_tab, qi, Q, Wq, Hq, qx, qy) : tile_query<NL>(lv_tab, qi, Q);
     const int64_t pair = ((int64_t)c.b * Q + q) * heads + c.h;
-    const float* lp = loc + pair * (NL * P * 2);
-    const float* wp = attn_w + pair * (NL * P);
     float4 go0, go1;
     if (ROWS == 2) {
       const unsigned short* gp = reinterpret_cast<const unsigned short*>(grad_out) + pair * D + j * 4;
@@ -231,94 +261,132 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_lw_kernel(
       go0 = ld4g(grad_out + pair * D + j * 4);
       go1 = ld4g(grad_out + pair * D + 16 + j * 4);
     }
+    const f32x2 gp[4] = {{go0.x, go0.y}, {go0.z, go0.w}, {go1.x, go1.y}, {go1.z, go1.w}};
     // ROWS: this (query, head)'s piece of the token's row: offsets at off_e, logits at log_e (element indices)
     const int64_t row_e = ((int64_t)c.b * Q + q) * (heads * NL * P * 3);
     const int64_t off_e = row_e + c.h * (NL * P * 2), log_e = row_e + heads * (NL * P * 2) + c.h * (NL * P);
-    float awr[NL * P];
-    if (ROWS) {
-      load_logits<ROWS, NL * P>(loc, log_e, awr);
-      softmax_regs<NL * P>(awr);
+    // this lane's points (level l, point j): attention weight, (ROWS) raw offset
+    float awl[NL];
+    float2 ofl[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (ROWS == 2) {
+        awl[l] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(loc)[log_e + l * P + j] << 16);
+        ofl[l] = load_offset<2>(loc, off_e + (l * P + j) * 2);
+      } else if (ROWS == 1) {
+        awl[l] = loc[log_e + l * P + j];
+        ofl[l] = load_offset<1>(loc, off_e + (l * P + j) * 2);
+      } else {
+        awl[l] = attn_w[pair * (NL * P) + l * P + j];
+        ofl[l] = *reinterpret_cast<const float2*>(loc + (pair * (NL * P) + l * P + j) * 2);
+      }
     }
-    float gwa[NL * P], gxa[NL * P], gya[NL * P];
+    if (ROWS) {  // softmax over the (query, head)'s NL * P logits: NL per lane, the quad holds them all (HF:986-991)
+      float mx = awl[0];
+#pragma unroll
+      for (int l = 1; l < NL; ++l) mx = fmaxf(mx, awl[l]);
+      mx = quad_max_dpp(mx);
+      float sm = 0.f;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        awl[l] = __expf(awl[l] - mx);
+        sm += awl[l];
+      }
+      const float inv = __builtin_amdgcn_rcpf(quad_sum_dpp(sm));  // as the forward kernel's prologue
+#pragma unroll
+      for (int l = 0; l < NL; ++l) awl[l] *= inv;
+    }
+    float gwl[NL], gxl[NL], gyl[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const int Wl = g.w[l], Hl = g.h[l], ww = g.win_w[l], wh = g.win_h[l];
       const float4* wl = win + g.lds_off4[l] + j;
       const float* vlev = vb + (int64_t)g.start[l] * row_stride + j * 4;
-      float4 aw4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!ROWS) aw4 = ld4g(wp + l * P);
-      // ROWS: the query's reference pixel at this level, see above
-      const float rpx = ((float)qx + 0.5f) * ((float)Wl / (float)Wq) - 0.5f, rpy = ((float)qy + 0.5f) * ((float)Hl / (float)Hq) - 0.5f;
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        float aw, x, y;
-        if (ROWS) {
-          const float2 of = load_offset<ROWS>(loc, off_e + (l * P + p) * 2);
-          aw = awr[l * P + p];
-          x = rpx + of.x;
-          y = rpy + of.y;
-        } else {
-          const float2 lc = *reinterpret_cast<const float2*>(lp + (l * P + p) * 2);
-          aw = p == 0 ? aw4.x : p == 1 ? aw4.y : p == 2 ? aw4.z : aw4.w;
-          pixel_coords(lc.x, lc.y, Wl, Hl, x, y);
-        }
-        const float x0f = floorf(x), y0f = floorf(y);
-        const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
-        const int xr = (int)x0f - c.wx0[l], yr = (int)y0f - c.wy0[l];
-        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
-        if ((unsigned)xr < (unsigned)(ww - 1) && (unsigned)yr < (unsigned)(wh - 1)) {
-          const float4* cc = wl + (yr * ww + xr) * 8;
-          d00 = dot8(go0, go1, cc[0], cc[4]);
-          d01 = dot8(go0, go1, cc[8], cc[12]);
-          d10 = dot8(go0, go1, cc[ww * 8], cc[ww * 8 + 4]);
-          d11 = dot8(go0, go1, cc[ww * 8 + 8], cc[ww * 8 + 12]);
-        } else if (x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl) {  // general path, global loads
-          const int x0 = (int)x0f, y0 = (int)y0f;
-          const bool xl = x0 >= 0, xr2 = x0 + 1 < Wl, yt = y0 >= 0, yb = y0 + 1 < Hl;
-          const float* p00 = vlev + (int64_t)(y0 * Wl + x0) * row_stride;
+      float x, y;
+      if (ROWS) {  // the query's reference pixel at this level (see load_logits) + the offset
+        x = (((float)qx + 0.5f) * ((float)Wl / (float)Wq) - 0.5f) + ofl[l].x;
+        y = (((float)qy + 0.5f) * ((float)Hl / (float)Hq) - 0.5f) + ofl[l].y;
+      } else {
+        pixel_coords(ofl[l].x, ofl[l].y, Wl, Hl, x, y);
+      }
+      const float x0f = floorf(x), y0f = floorf(y);
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const int xr = x0 - c.wx0[l], yr = y0 - c.wy0[l];
+      const bool inside = x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl;
+      const bool inwin = (unsigned)xr < (unsigned)(ww - 1) && (unsigned)yr < (unsigned)(wh - 1);
+      // The quad walks the level's four points WITHOUT branches: a point that is not in the window is read at window address 0
+      // and its sums are dropped, so that the reads of point K + 1 can be issued under the dot products of point K (with a
+      // branch per point every walk paid its own LDS latency).  Points in the image but outside the window -- rare -- are
+      // redone from global memory behind a wave-uniform test.
+      const int addr = inwin ? (yr * ww + xr) * 8 : 0;
+      float m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f;  // this lane's point: the four corner dot products
+      auto walk = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        const float4* cc = wl + bcast_dpp<K>(addr);
+        const float d00 = quad_sum_dpp(dot8p(gp, cc[0], cc[4]));
+        const float d01 = quad_sum_dpp(dot8p(gp, cc[8], cc[12]));
+        const float d10 = quad_sum_dpp(dot8p(gp, cc[ww * 8], cc[ww * 8 + 4]));
+        const float d11 = quad_sum_dpp(dot8p(gp, cc[ww * 8 + 8], cc[ww * 8 + 12]));
+        if (j == K) { m00 = d00; m01 = d01; m10 = d10; m11 = d11; }
+      };
+      walk(std::integral_constant<int, 0>{});
+      walk(std::integral_constant<int, 1>{});
+      walk(std::integral_constant<int, 2>{});
+      walk(std::integral_constant<int, 3>{});
+      if (!inwin) m00 = m01 = m10 = m11 = 0.f;
+      const bool far = inside && !inwin;
+      if (__builtin_amdgcn_ballot_w64(far) != 0) {  // general path, global loads
+        auto walk_far = [&](auto kc) __attribute__((always_inline)) {
+          constexpr int K = decltype(kc)::value;
+          if (!bcast_dpp<K>((int)far)) return;  // (quad-uniform)
+          const int kx0 = bcast_dpp<K>(x0), ky0 = bcast_dpp<K>(y0);
+          const bool xl = kx0 >= 0, xr2 = kx0 + 1 < Wl, yt = ky0 >= 0, yb = ky0 + 1 < Hl;
+          const float* p00 = vlev + (int64_t)(ky0 * Wl + kx0) * row_stride;
+          float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
           if (yt && xl) d00 = dot8(go0, go1, ld4g(p00), ld4g(p00 + 16));
           if (yt && xr2) d01 = dot8(go0, go1, ld4g(p00 + row_stride), ld4g(p00 + row_stride + 16));
           if (yb && xl) d10 = dot8(go0, go1, ld4g(p00 + (int64_t)Wl * row_stride), ld4g(p00 + (int64_t)Wl * row_stride + 16));
           if (yb && xr2)
             d11 = dot8(go0, go1, ld4g(p00 + (int64_t)(Wl + 1) * row_stride), ld4g(p00 + (int64_t)(Wl + 1) * row_stride + 16));
-        }
-        d00 = quad_sum(d00);
-        d01 = quad_sum(d01);
-        d10 = quad_sum(d10);
-        d11 = quad_sum(d11);
-        const bool inside = x > -1.f && x < (float)Wl && y > -1.f && y < (float)Hl;
-        // d pixel / d location = (W_l, H_l); d pixel / d offset = 1 (ROWS)
-        const float sx = ROWS ? aw : aw * (float)Wl, sy = ROWS ? aw : aw * (float)Hl;
-        gwa[l * P + p] = inside ? fy0 * (fx0 * d00 + fx1 * d01) + fy1 * (fx0 * d10 + fx1 * d11) : 0.f;
-        gxa[l * P + p] = inside ? sx * (fy0 * (d01 - d00) + fy1 * (d11 - d10)) : 0.f;
-        gya[l * P + p] = inside ? sy * (fx0 * (d10 - d00) + fx1 * (d11 - d01)) : 0.f;
+          d00 = quad_sum_dpp(d00);
+          d01 = quad_sum_dpp(d01);
+          d10 = quad_sum_dpp(d10);
+          d11 = quad_sum_dpp(d11);
+          if (j == K) { m00 = d00; m01 = d01; m10 = d10; m11 = d11; }
+        };
+        walk_far(std::integral_constant<int, 0>{});
+        walk_far(std::integral_constant<int, 1>{});
+        walk_far(std::integral_constant<int, 2>{});
+        walk_far(std::integral_constant<int, 3>{});
       }
-      if (!ROWS && j == 0) {
-        *reinterpret_cast<float4*>(grad_w + pair * (NL * P) + l * P) = make_float4(gwa[l * P], gwa[l * P + 1], gwa[l * P + 2], gwa[l * P + 3]);
-        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2) = make_float4(gxa[l * P], gya[l * P], gxa[l * P + 1], gya[l * P + 1]);
-        *reinterpret_cast<float4*>(grad_loc + (pair * (NL * P) + l * P) * 2 + 4) = make_float4(gxa[l * P + 2], gya[l * P + 2], gxa[l * P + 3], gya[l * P + 3]);
+      const float fx1 = x - x0f, fy1 = y - y0f, fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+      const float aw = awl[l];
+      // d pixel / d location = (W_l, H_l); d pixel / d offset = 1 (ROWS)
+      const float sx = ROWS ? aw : aw * (float)Wl, sy = ROWS ? aw : aw * (float)Hl;
+      gwl[l] = inside ? fy0 * (fx0 * m00 + fx1 * m01) + fy1 * (fx0 * m10 + fx1 * m11) : 0.f;
+      gxl[l] = inside ? sx * (fy0 * (m01 - m00) + fy1 * (m11 - m10)) : 0.f;
+      gyl[l] = inside ? sy * (fx0 * (m10 - m00) + fx1 * (m11 - m01)) : 0.f;
+      if (!ROWS) {
+        grad_w[pair * (NL * P) + l * P + j] = gwl[l];
+        *reinterpret_cast<float2*>(grad_loc + (pair * (NL * P) + l * P + j) * 2) = make_float2(gxl[l], gyl[l]);
       }
     }
     if (ROWS) {
-      // softmax backward: d logit_i = w_i (g_i - sum_k w_k g_k); then lane l of the quad stores level l's 8 offset and 4 logit gradients
+      // softmax backward: d logit_i = w_i (g_i - sum_k w_k g_k)
       float sdot = 0.f;
 #pragma unroll
-      for (int i = 0; i < NL * P; ++i) sdot += awr[i] * gwa[i];
-#pragma unroll
-      for (int i = 0; i < NL * P; ++i) gwa[i] = awr[i] * (gwa[i] - sdot);
+      for (int l = 0; l < NL; ++l) sdot += awl[l] * gwl[l];
+      sdot = quad_sum_dpp(sdot);
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        if (j != (l & 3)) continue;
-        const int i0 = l * P;
+        const float gl = awl[l] * (gwl[l] - sdot);
         if (ROWS == 2) {
           unsigned short* gr = reinterpret_cast<unsigned short*>(grad_loc);
-          *reinterpret_cast<uint4*>(gr + off_e + i0 * 2) = make_uint4(pack_bf16_b(gxa[i0], gya[i0]), pack_bf16_b(gxa[i0 + 1], gya[i0 + 1]),
-                                                                       pack_bf16_b(gxa[i0 + 2], gya[i0 + 2]), pack_bf16_b(gxa[i0 + 3], gya[i0 + 3]));
-          *reinterpret_cast<uint2*>(gr + log_e + i0) = make_uint2(pack_bf16_b(gwa[i0], gwa[i0 + 1]), pack_bf16_b(gwa[i0 + 2], gwa[i0 + 3]));
+          *reinterpret_cast<unsigned*>(gr + off_e + (l * P + j) * 2) = pack_bf16_b(gxl[l], gyl[l]);
+          gr[log_e + l * P + j] = (unsigned short)(pack_bf16_b(gl, 0.f) & 0xffffu);
         } else {
-          *reinterpret_cast<float4*>(grad_loc + off_e + i0 * 2) = make_float4(gxa[i0], gya[i0], gxa[i0 + 1], gya[i0 + 1]);
-          *reinterpret_cast<float4*>(grad_loc + off_e + i0 * 2 + 4) = make_float4(gxa[i0 + 2], gya[i0 + 2], gxa[i0 + 3], gya[i0 + 3]);
-          *reinterpret_cast<float4*>(grad_loc + log_e + i0) = make_float4(gwa[i0], gwa[i0 + 1], gwa[i0 + 2], gwa[i0 + 3]);
+          *reinterpret_cast<float2*>(grad_loc + off_e + (l * P + j) * 2) = make_float2(gxl[l], gyl[l]);
+          grad_loc[log_e + l * P + j] = gl;
         }
       }
     }
@@ -585,7 +653,12 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
     const int64_t row_e = ((int64_t)c.b * Q + q) * (heads * NP * 3);
     const int64_t off_e = row_e + c.h * (NP * 2), log_e = row_e + heads * (NP * 2) + c.h * NP;
     float awr[NP];
+    float2 ofr[NP];  // ROWS: the unit's offsets, requested together with the logits (loaded point by point, behind each point's
+                     // branches, every point paid its own trip to L2)
     if (ROWS) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (NSPLIT == 1 || i % NSPLIT == part_pts) ofr[i] = load_offset<ROWS>(loc, off_e + i * 2);
       load_logits<ROWS, NP>(loc, log_e, awr);
       softmax_regs<NP>(awr);
     }
@@ -599,7 +672,7 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_value_quad_kernel(
         if (NSPLIT > 1 && (l * P + p) % NSPLIT != part_pts) continue;  // wave-uniform
         float aw, x, y;
         if (ROWS) {
-          const float2 of = load_offset<ROWS>(loc, off_e + (l * P + p) * 2);
+          const float2 of = ofr[l * P + p];
           aw = valid ? awr[l * P + p] : 0.f;
           x = rpx + of.x;
           y = rpy + of.y;
@@ -832,7 +905,24 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
     if ((2 * reach + 1) * (2 * reach + 1) > 64 || heads * 32 < 64) return WM2F_OK;  // the gather tests its candidates one per lane
   }
   if (rows) {
-    auto ka = rows == 2 ? msdeform_tiled_bwd_lw_kernel<3, 4, 2> : msdeform_tiled_bwd_lw_kernel<3, 4, 1>;
+    // 16 waves per workgroup (110 registers per lane): 2-3 % faster than 8 on the same box (2450 / 2467 / 2485 against 2503 / 2538 /
+    // 2552 us for the whole backward at config 2), 12 waves in between
+    auto ka = rows == 2 ? msdeform_tiled_bwd_lw_kernel<3, 4, 2, 1024> : msdeform_tiled_bwd_lw_kernel<3, 4, 1, 1024>;
+    int ka_threads = 1024;
+#ifdef WM2F_PROFILING
+    const char* e_lw = getenv("WM2F_K1_LW_THREADS");  // profiling build: 8 / 12 waves per workgroup, for A/B
+    if (e_lw && atoi(e_lw) == 512) {
+      ka = rows == 2 ? msdeform_tiled_bwd_lw_kernel<3, 4, 2, 512> : msdeform_tiled_bwd_lw_kernel<3, 4, 1, 512>;
+      ka_threads = 512;
+    }
+    if (e_lw && atoi(e_lw) == 768) {
+      ka = rows == 2 ? msdeform_tiled_bwd_lw_kernel<3, 4, 2, 768> : msdeform_tiled_bwd_lw_kernel<3, 4, 1, 768>;
+      ka_threads = 768;
+    }
+    if (e_lw && atoi(e_lw) == 1 && rows == 2) ka = msdeform_tiled_bwd_lw_kernel<3, 4, 2, 1024, 1>;  // timing ablations
+    if (e_lw && atoi(e_lw) == 2 && rows == 2) ka = msdeform_tiled_bwd_lw_kernel<3, 4, 2, 1024, 2>;
+    const bool skip_kb = e_lw && atoi(e_lw) == 3;  // the lw kernel alone
+#endif
     auto kb = rows == 2 ? msdeform_tiled_bwd_value_quad_kernel<3, 4, false, kQuadBwdThreads, 2, 2>
                         : msdeform_tiled_bwd_value_quad_kernel<3, 4, false, kQuadBwdThreads, 2, 1>;
     if (p.lds_bytes > 64 * 1024) {
@@ -843,8 +933,11 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
         return WM2F_ELAUNCH;
       }
     }
-    hipLaunchKernelGGL(ka, dim3(per_xcd * kNumXcd), dim3(kBwdThreads), p.lds_bytes, st, (const float*)value, (const float*)loc,
+    hipLaunchKernelGGL(ka, dim3(per_xcd * kNumXcd), dim3(ka_threads), p.lds_bytes, st, (const float*)value, (const float*)loc,
                        (const float*)nullptr, (const float*)grad_out, (float*)grad_loc, (float*)nullptr, p.g, S, Q, heads, (int)n_logical, per_xcd);
+#ifdef WM2F_PROFILING
+    if (!(skip_kb || (e_lw && (atoi(e_lw) == 1 || atoi(e_lw) == 2))))
+#endif
     hipLaunchKernelGGL(kb, dim3(per_xcd * kNumXcd), dim3(kQuadBwdThreads), p.lds_bytes, st, (const float*)loc, (const float*)nullptr,
                        (const float*)grad_out, (float*)grad_value, (float*)nullptr, (long long*)nullptr, (const int*)nullptr, p.g, S, Q, heads,
                        (int)n_logical, per_xcd);
