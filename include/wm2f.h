@@ -259,9 +259,12 @@ int wm2f_masked_xattn_bf16_bwd(const void* q, const void* k, const void* v, cons
  *   tgt_classes  int64 [sum T_i]
  *   points       (NL, B, P, 2) fp32 in [0,1] as (x, y)
  *   cost         (NL, B, Q, Tmax) fp32; columns >= T_i are left untouched
- *   workspace    fp32 scratch, at least wm2f_matcher_workspace(...) bytes
+ *   workspace    scratch, at least wm2f_matcher_workspace(...) bytes (sampled targets, the grouped points, band offsets)
  * cost = w_mask*BCE_pair + w_class*(-softmax(class)[:, tgt]) + w_dice*dice_pair, clamped to
  * +-1e10 with NaN -> 0.
+ * The points may come in any order (the cost is a sum over them): with P >= 1024 and maps up to ~2000 wide the call groups
+ * each (level, image)'s points by band of map rows (stable, so results are reproducible) and samples the predictions from LDS
+ * bands instead of gathering from memory.
  */
 int64_t wm2f_matcher_workspace(int NL, int B, int Q, int P, int Tsum);
 int wm2f_matcher_cost(const void* mask_logits, const void* class_logits, const void* tgt_masks,

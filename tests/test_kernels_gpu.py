@@ -736,6 +736,35 @@ def test_k4_multi_level_ragged(ops):
         off += counts[b]
 
 
+@pytest.mark.parametrize("h,w,P,counts", [(300, 500, 2000, [20, 3]), (120, 501, 1100, [2, 17]), (64, 64, 1024, [5, 0])])
+def test_k4_band_form(ops, h, w, P, counts):
+    """P >= 1024: wm2f_matcher_cost groups the points by band of map rows and samples the predictions from LDS (18 / 4 bands / one
+    band here; widths with and without 16-byte rows; more than 16 targets = two target chunks; an image without targets; points
+    outside [0, 1], on the first row and beyond the last).  Same cost as the oracle, identical bits on a second run (the grouping
+    is a stable counting sort), and the same cost for the points in another order up to summation order."""
+    g = torch.Generator().manual_seed(18)
+    NL, B, Q, Ht, Wt, C1 = 2, 2, 7, 96, 80, 4
+    ml = torch.randn(NL, B, Q, h, w, generator=g) * 2
+    cl = torch.randn(NL, B, Q, C1, generator=g)
+    tgt = (torch.rand(sum(counts), Ht, Wt, generator=g) < 0.3).float()
+    cls = torch.randint(0, C1 - 1, (sum(counts),), generator=g)
+    pts = torch.rand(NL, B, P, 2, generator=g) * 1.1 - 0.05
+    pts[:, :, :4, 1] = torch.tensor([0.0, 0.2 / h, 1.0, 1.0 - 0.2 / h])
+    args = (dev(ml), dev(cl), dev(tgt), counts, dev(cls))
+    cost = ops.matcher_cost(*args, dev(pts), 2.0, 5.0, 5.0)
+    assert torch.equal(cost, ops.matcher_cost(*args, dev(pts), 2.0, 5.0, 5.0))
+    perm = torch.randperm(P, generator=g)
+    torch.testing.assert_close(ops.matcher_cost(*args, dev(pts[:, :, perm].contiguous()), 2.0, 5.0, 5.0), cost, rtol=1e-5, atol=1e-5)
+    cost, off = cost.cpu(), 0
+    for b in range(B):
+        for lvl in range(NL):
+            if counts[b]:
+                ref = O.matcher_cost(ml[lvl, b], cl[lvl, b], tgt[off:off + counts[b]], cls[off:off + counts[b]],
+                                     pts[lvl, b:b + 1], 2.0, 5.0, 5.0)
+                torch.testing.assert_close(cost[lvl, b, :, :counts[b]], ref, rtol=1e-5, atol=1e-5)
+        off += counts[b]
+
+
 # ----------------------------------------------------------------------------------------- point sampling
 def test_point_sample_fwd_bwd(ops):
     g = torch.Generator().manual_seed(9)

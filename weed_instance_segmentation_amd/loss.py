@@ -160,7 +160,6 @@ class Mask2FormerLoss(nn.Module):
         # mask losses on the matched queries' rows recomputed by one einsum (matched_row_logits) instead of the dense
         # predictions; this attribute = False restores the dense route (A/B runs and tests)
         self.matched_row_masks = True
-        self.sort_matcher_points = True  # see match()
         self.device_lsa = True  # ops.lsa_batched instead of scipy on a host copy (same indices); False: the host route
         self.cost_class, self.cost_mask, self.cost_dice = config.class_weight, config.mask_weight, config.dice_weight
         self.world_size_fn = None  # set by parallel.DataParallelEngine: all-reduces num_masks (HF:781-794)
@@ -175,18 +174,9 @@ class Mask2FormerLoss(nn.Module):
             return [[(e, e) for _ in range(B)] for _ in range(NL)]
         ml = [m.detach().float() for m in all_masks]  # used where they are: a stacked copy is 10 x 210 MB at config 2
         cl = torch.stack([c.detach() for c in all_classes]) if NL > 1 else all_classes[0].detach()[None]
-        if self.sort_matcher_points and points.is_cuda:
-            # The cost sums over the P random points of an (image, level) do not depend on their order; sorted by the pixel
-            # they fall on, the 64 points of a wave gather from a dozen cache lines instead of ~250 (the gathers, not the
-            # arithmetic, were the matcher kernel's time: 3.4 ms at config 2).
-            # ONE flat radix sort with the (level, image) segment in the key's high bits -- a segmented argsort of the same 2 M keys
-            # took 1.4 ms per config-2 step
-            h, w = ml[0].shape[-2:]
-            n_seg, n_pts = points.shape[0] * points.shape[1], points.shape[2]
-            key = ((points[..., 1] * h).floor().clamp_(0, h - 1) * w + (points[..., 0] * w).floor().clamp_(0, w - 1)).long()
-            key = key.view(n_seg, n_pts) + torch.arange(n_seg, device=points.device)[:, None] * (h * w)
-            order = torch.sort(key.view(-1))[1]  # sorted keys are grouped by segment: order[s * P : (s + 1) * P] lie in segment s
-            points = points.reshape(n_seg * n_pts, 2)[order].view(points.shape).contiguous()
+        # (the cost sums over the P random points of an (image, level) do not depend on their order: wm2f_matcher_cost groups
+        # them by map band itself and samples from LDS -- csrc/matcher.hip, band form; a sort of the points by pixel used to
+        # stand here, 1.4 ms per config-2 step)
         cost = ops.matcher_cost(ml if NL <= 16 else torch.stack(ml), cl.float(), tgt, counts, cls, points, self.cost_class,
                                 self.cost_mask, self.cost_dice)
         Q = cost.shape[2]
