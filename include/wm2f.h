@@ -390,6 +390,15 @@ int wm2f_bias_relu_maxpool(const void* x, const void* bias, void* y, int N, int 
 int wm2f_group_norm_act(const void* x, const void* gamma, const void* beta, const void* up, void* y, void* stats_ws,
                         int B, int C, int G, int H, int W, int Hs, int Ws, float eps, int relu, void* stream);
 
+/* Importance sampling of the mask losses, HF:688-704 (sample_points_using_uncertainty): the points of the k largest scores of
+ * each row -- gather(coords, topk(uncertainty, k)[1]) -- by radix selection in LDS instead of the sort a stock top-k of
+ * thousands is.
+ *   score (rows, n) fp32; pts (rows, n, 2) fp32; out (rows, out_row_points, 2) fp32: entries [0, k) of each row are written,
+ *   in INDEX order (the losses sum over points, so only the set matters); equal scores at the threshold: lowest indices first;
+ *   NaN ranks highest (as torch.topk).  n <= 38400 (the row's keys live in LDS), else WM2F_EUNSUPPORTED. */
+int wm2f_select_top_points(const void* score, const void* pts, void* out, int rows, int n, int k, int out_row_points,
+                           void* stream);
+
 /* ---- point-sampled mask loss, batched over the prediction levels --------
  * Replaces, for all levels of a step in one launch each, the per-level tensor work of Mask2FormerLoss.loss_masks
  * (HF:580-640) with sample_points_using_uncertainty (HF:671-724), sample_point (HF:245-274),

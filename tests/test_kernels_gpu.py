@@ -765,6 +765,31 @@ def test_k4_band_form(ops, h, w, P, counts):
         off += counts[b]
 
 
+@pytest.mark.parametrize("R,n,k", [(7, 37632, 9408), (3, 1000, 250), (2, 64, 64), (5, 5000, 1), (4, 2049, 2048)])
+def test_select_top_points_equals_topk_set(ops, R, n, k):
+    """wm2f_select_top_points: the SET torch.topk returns (HF:688-704), written in index order; ties at the threshold go to the
+    lowest indices; NaN ranks highest; entries beyond k are the caller's."""
+    g = torch.Generator().manual_seed(23)
+    score = -torch.randn(R, n, generator=g).abs()
+    score[0, : n // 2] = torch.round(score[0, : n // 2] * 4) / 4  # many exact ties, some at the threshold
+    if n > 100:
+        score[1, 17] = float("nan")
+        score[1, 5] = 0.0
+        score[-1, :] = -1.0  # a constant row: the first k indices
+    pts = torch.rand(R, n, 2, generator=g)
+    out = ops.select_top_points(dev(score), dev(pts), k, k + 3).cpu()
+    assert out.shape == (R, k + 3, 2)
+    key = torch.where(torch.isnan(score), torch.full_like(score, float("inf")), score)
+    # the reference set: sort by (score descending, index ascending), take k, then index order
+    order = torch.sort(-key.double() * 1.0, dim=1, stable=True)[1][:, :k]
+    ref_idx = torch.sort(order, dim=1)[0]
+    ref = torch.gather(pts, 1, ref_idx[..., None].expand(-1, -1, 2))
+    assert torch.equal(out[:, :k], ref)
+    # and it is a top-k set in torch's sense: same multiset of scores as torch.topk
+    tk = torch.topk(key, k, dim=1)[0]
+    assert torch.equal(torch.sort(torch.gather(key, 1, ref_idx), dim=1, descending=True)[0], tk)
+
+
 # ----------------------------------------------------------------------------------------- point sampling
 def test_point_sample_fwd_bwd(ops):
     g = torch.Generator().manual_seed(9)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "wm2f_msdeform_fused_packed_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fused_lanes_fwd": (c_int, [_P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm2f_msdeform_fwd_v": (c_int, [_P, _P, _P, _P, _P, _HOST_I32, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm2f_select_top_points": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_levels_fwd": (c_int, [POINTER(c_void_p), _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_levels_bwd": (c_int, [_P, _P, _P, POINTER(c_void_p), _I, _I, _I, _I, _I, _P]),
     "wm2f_point_sample_levels_bwd_unique": (c_int, [_P, _P, _P, POINTER(c_void_p), _I, _I, _I, _I, _I, _P]),

@@ -233,6 +233,155 @@ __global__ __launch_bounds__(256) void mask_loss_rows_bwd_kernel(const float* __
 
 using namespace wm2f;
 
+// ---------------------------------------------------------------------------------- importance sampling: the k most uncertain points
+// HF:688-704 (sample_points_using_uncertainty): idx = topk(uncertainty, k)[1]; points = gather(coords, idx).  A top-k with k in the
+// thousands is a full sort in the stock library (one segmented radix sort of 2560 x 37632 keys: 1.4 ms per config-2 step).  The
+// losses that follow are sums over the points, so only the SET matters: a workgroup per row holds the row's keys in LDS,
+// finds the k-th largest by radix selection (four 8-bit digits, most significant first, one 256-bin histogram each) and writes
+// the selected points in index order (equal keys at the threshold: lowest indices first).  NaN ranks highest, as in torch.topk.
+namespace wm2f {
+namespace {
+
+constexpr int kSelThreads = 1024;
+constexpr int kSelMaxN = 38400;  // keys per row that fit LDS (150 KiB)
+
+__device__ __forceinline__ unsigned sel_key(float v) {  // larger float (NaN largest) -> larger unsigned
+  const unsigned u = __float_as_uint(v);
+  if (v != v) return 0xffffffffu;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(kSelThreads) void select_top_points_kernel(const float* __restrict__ score, const float* __restrict__ pts,
+                                                                        float* __restrict__ out, int n, int k, int out_row_floats) {
+  extern __shared__ unsigned keys[];  // [n]
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_krem, wcnt[2][2][kSelThreads / 64];  // [ping-pong][greater / equal][wave]
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* sc = score + (int64_t)row * n;
+  const float2* pr = reinterpret_cast<const float2*>(pts) + (int64_t)row * n;
+  float2* po = reinterpret_cast<float2*>(out + (int64_t)row * out_row_floats);
+  // (eight loads in flight per lane: one at a time, this loop alone was 37 trips to memory per row)
+  for (int i0 = tid; i0 < n; i0 += 8 * kSelThreads) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = i0 + e * kSelThreads < n ? sc[i0 + e * kSelThreads] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (i0 + e * kSelThreads < n) keys[i0 + e * kSelThreads] = sel_key(v[e]);
+  }
+  if (tid == 0) {
+    s_prefix = 0u;
+    s_krem = k;
+  }
+  // radix selection: after the round of digit d, s_prefix holds the top (d + 1) digits of the k-th largest key and s_krem how
+  // many keys with exactly that prefix are still to be taken
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i0 = 0; i0 < n; i0 += kSelThreads) {
+      const int i = i0 + tid;
+      const unsigned key = i < n ? keys[i] : 0u;
+      bool live = i < n && (key & himask) == prefix;
+      const int bin = (int)((key >> shift) & 255u);
+      // The scores of one row share sign and exponent: in the first rounds nearly every lane of a wave hits ONE bin, and 64 LDS
+      // atomics on one address run one after the other (the first form of this kernel took as long as the sort it replaces).
+      // "The first live lane's bin: one add of its population count" takes those lanes out; what is left is spread.
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+      if (m == 0) continue;  // (uniform: from the third digit on almost every wave, almost every time)
+      const int first = __builtin_ctzll(m), lead = __builtin_amdgcn_readlane(bin, first);
+      const unsigned long long same = __builtin_amdgcn_ballot_w64(live && bin == lead);
+      if (lane == first) atomicAdd(&hist[lead], __builtin_popcountll(same));
+      if (live && bin != lead) atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rem = s_krem, d = 255;
+      for (; d > 0; --d) {
+        if (hist[d] >= rem) break;
+        rem -= hist[d];
+      }
+      s_prefix = prefix | ((unsigned)d << shift);
+      s_krem = rem;
+    }
+    __syncthreads();
+  }
+  const unsigned thr = s_prefix;  // the k-th largest key; eq_take of the keys equal to it are taken, lowest indices first
+  const int eq_take = s_krem;
+  // compaction in index order: position = selected before me = greater before me + min(equal before me, eq_take)
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int gt_seen = 0, eq_seen = 0;  // over the chunks so far (every thread keeps the same totals)
+  for (int c0 = 0, pp = 0; c0 < n; c0 += kSelThreads, pp ^= 1) {
+    const int i = c0 + tid;
+    const unsigned key = i < n ? keys[i] : 0u;
+    const bool gt = i < n && key > thr, eq = i < n && key == thr;
+    const unsigned long long mg = __builtin_amdgcn_ballot_w64(gt), me = __builtin_amdgcn_ballot_w64(eq);
+    if (lane == 0) {
+      wcnt[pp][0][wave] = __builtin_popcountll(mg);
+      wcnt[pp][1][wave] = __builtin_popcountll(me);
+    }
+    __syncthreads();  // (one barrier per chunk: the counts ping-pong between two buffers)
+    int gt_before = gt_seen + __builtin_popcountll(mg & lt), eq_before = eq_seen + __builtin_popcountll(me & lt);
+    int gt_total = 0, eq_total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
+      const int cg = wcnt[pp][0][w2], ce = wcnt[pp][1][w2];
+      if (w2 < wave) {
+        gt_before += cg;
+        eq_before += ce;
+      }
+      gt_total += cg;
+      eq_total += ce;
+    }
+    // the output position replaces the key (0xffffffff: not selected); the copies follow in a loop without barriers
+    if (i < n) keys[i] = (gt || (eq && eq_before < eq_take)) ? (unsigned)(gt_before + (eq_before < eq_take ? eq_before : eq_take)) : 0xffffffffu;
+    gt_seen += gt_total;
+    eq_seen += eq_total;
+  }
+  // (each thread reads back only what it wrote itself: no barrier needed)
+  for (int i0 = tid; i0 < n; i0 += 8 * kSelThreads) {
+    float2 v[8];
+    unsigned pos[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e * kSelThreads;
+      pos[e] = i < n ? keys[i] : 0xffffffffu;
+      if (pos[e] != 0xffffffffu) v[e] = pr[i];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (pos[e] != 0xffffffffu) po[pos[e]] = v[e];
+  }
+}
+
+}  // namespace
+}  // namespace wm2f
+
+extern "C" int wm2f_select_top_points(const void* score, const void* pts, void* out, int rows, int n, int k, int out_row_points,
+                                      void* stream) {
+  const char* who = "wm2f_select_top_points";
+  WM2F_REQUIRE(score && pts && out, "%s: null pointer", who);
+  WM2F_REQUIRE(rows > 0 && n > 0 && k > 0 && k <= n && out_row_points >= k, "%s: sizes", who);
+  if (n > wm2f::kSelMaxN) {
+    wm2f::set_error("%s: %d candidates per row exceed %d (use a sort)", who, n, wm2f::kSelMaxN);
+    return WM2F_EUNSUPPORTED;
+  }
+  const size_t lds = (size_t)n * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wm2f::select_top_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wm2f::kSelMaxN * 4) != hipSuccess) {
+      wm2f::set_error("%s: cannot reserve %d bytes of LDS", who, wm2f::kSelMaxN * 4);
+      return WM2F_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wm2f::select_top_points_kernel, dim3(rows), dim3(wm2f::kSelThreads), lds, (hipStream_t)stream, (const float*)score,
+                     (const float*)pts, (float*)out, n, k, out_row_points * 2);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
 extern "C" int wm2f_point_sample_levels_fwd(const void* const* level_maps, int n_levels, const void* pts, const int32_t* index,
                                             void* out, int M, int H, int W, int P, int neg_abs, void* stream) {
   const char* who = "wm2f_point_sample_levels_fwd";

@@ -194,6 +194,19 @@ class Mask2FormerLoss(nn.Module):
             indices.append(per)
         return indices
 
+    @staticmethod
+    def _uncertain_points(unc, pc, n_unc, P):
+        """HF:688-704: the n_unc most uncertain of the oversampled points, as the first n_unc entries of a (rows, P, 2) tensor
+        (the rest is the caller's: random points).  On the GPU a radix selection (ops.select_top_points: the set topk returns,
+        in index order -- the losses sum over points); on the CPU the dependency's topk + gather."""
+        if unc.is_cuda and n_unc > 0:
+            return ops.select_top_points(unc.float().contiguous(), pc.float().contiguous(), n_unc, P)
+        pts = torch.empty(unc.shape[0], P, 2, device=unc.device, dtype=pc.dtype)
+        if n_unc > 0:
+            idx = torch.topk(unc, k=n_unc, dim=1)[1]
+            pts[:, :n_unc] = torch.gather(pc, 1, idx[..., None].expand(-1, -1, 2))
+        return pts
+
     # ---------------------------------------------------------------- per-level losses
     def _num_masks(self, counts, device):
         n = torch.full((), float(sum(counts)), dtype=torch.float, device=device)  # (a fill, not a host-to-device copy)
@@ -253,11 +266,9 @@ class Mask2FormerLoss(nn.Module):
         with torch.no_grad():
             pc = provider.oversample_points(level, M, n_over)
             unc = -ops.point_sample(maps.detach(), pc, pred_idx).abs()
-            idx = torch.topk(unc, k=n_unc, dim=1)[1]
-            pts = torch.gather(pc, 1, idx[..., None].expand(-1, -1, 2))
+            pts = self._uncertain_points(unc, pc, n_unc, P)
             if P - n_unc > 0:
-                pts = torch.cat([pts, provider.random_points(level, M, P - n_unc)], 1)
-            pts = pts.contiguous()
+                pts[:, n_unc:] = provider.random_points(level, M, P - n_unc)
             point_labels = ops.point_sample(tgt, pts, tgt_idx)
         point_logits = ops.point_sample(maps, pts, pred_idx)
         bce = F.binary_cross_entropy_with_logits(point_logits, point_labels, reduction="none")
@@ -341,12 +352,9 @@ class Mask2FormerLoss(nn.Module):
         with torch.no_grad():
             pc = torch.stack([provider.oversample_points(lvl, M, n_over) for lvl in order])  # (NL, M, n_over, 2)
             unc = ops.point_sample_levels([m.detach() for m in maps], pc.view(*lv_shape, n_over, 2), pred_idx, neg_abs=True)
-            idx = torch.topk(unc.view(NL * M, n_over), k=n_unc, dim=1)[1]
-            pts = torch.gather(pc.view(NL * M, n_over, 2), 1, idx[..., None].expand(-1, -1, 2))
+            pts = self._uncertain_points(unc.view(NL * M, n_over), pc.view(NL * M, n_over, 2), n_unc, P)
             if P - n_unc > 0:
-                rnd = torch.stack([provider.random_points(lvl, M, P - n_unc) for lvl in order]).view(NL * M, P - n_unc, 2)
-                pts = torch.cat([pts, rnd], 1)
-            pts = pts.contiguous()
+                pts[:, n_unc:] = torch.stack([provider.random_points(lvl, M, P - n_unc) for lvl in order]).view(NL * M, P - n_unc, 2)
             point_labels = ops.point_sample(tgt, pts, tgt_idx.view(-1))
         point_logits = ops.point_sample_levels(maps, pts.view(*lv_shape, P, 2), pred_idx, unique_index=True)  # a one-to-one assignment: no map twice
         bce, dice = ops.mask_loss_rows(point_logits.view(NL * M, P), point_labels)

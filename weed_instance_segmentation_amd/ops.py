@@ -1178,6 +1178,27 @@ class _PointSampleLevels(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+def select_top_points(score: torch.Tensor, pts: torch.Tensor, k: int, out_points: int | None = None) -> torch.Tensor:
+    """The points of the k largest scores of each row (HF:688-704: `gather(coords, topk(uncertainty, k)[1])`), without the sort
+    a stock top-k of thousands is: score (R, n) fp32, pts (R, n, 2) -> (R, out_points or k, 2) whose first k entries are the
+    selected points in INDEX order (the losses sum over points: only the set matters; equal scores at the threshold: lowest
+    indices first; NaN ranks highest).  Entries k.. are left for the caller (the random points of HF:700-703).  No autograd."""
+    score, pts = _req(score, "score"), _req(pts, "pts")
+    R, n = score.shape
+    if pts.shape != (R, n, 2) or not 0 < k <= n:
+        raise ValueError(f"select_top_points: score {tuple(score.shape)} pts {tuple(pts.shape)} k {k}")
+    P = int(out_points) if out_points is not None else int(k)
+    out = torch.empty(R, P, 2, device=score.device, dtype=torch.float32)
+    with torch.cuda.device(score.device):
+        rc = _timed("select_top_points", score, lambda: load().wm2f_select_top_points(_p(score), _p(pts), _p(out), R, n, int(k), P, _stream(score)))
+    if rc == _lib.WM2F_EUNSUPPORTED:  # more candidates per row than LDS holds: the stock sort
+        idx = torch.topk(score, k=k, dim=1)[1]
+        out[:, :k] = torch.gather(pts, 1, idx[..., None].expand(-1, -1, 2))
+        return out
+    check(rc, "wm2f_select_top_points")
+    return out
+
+
 def point_sample_levels(maps, pts: torch.Tensor, index: torch.Tensor, neg_abs: bool = False, unique_index: bool = False) -> torch.Tensor:
     """sample_point (HF:245-274) on one (N,H,W) map tensor PER LEVEL without stacking them: pts (NL,M,P,2) in [0,1]
     (x,y), index (NL,M) int32 = which map of its level row m samples -> (NL,M,P).  neg_abs: -|value| (HF:688-690).
