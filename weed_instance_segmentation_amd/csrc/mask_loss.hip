@@ -256,7 +256,8 @@ __global__ __launch_bounds__(kSelThreads) void select_top_points_kernel(const fl
   extern __shared__ unsigned keys[];  // [n]
   __shared__ int hist[256];
   __shared__ unsigned s_prefix;
-  __shared__ int s_krem, wcnt[2][2][kSelThreads / 64];  // [ping-pong][greater / equal][wave]
+  __shared__ int s_krem, s_krem_next, wcnt[2][kSelThreads / 64];  // [greater / equal][wave]
+  __shared__ int hsuf[256], wtot[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* sc = score + (int64_t)row * n;
   const float2* pr = reinterpret_cast<const float2*>(pts) + (int64_t)row * n;
@@ -296,50 +297,72 @@ __global__ __launch_bounds__(kSelThreads) void select_top_points_kernel(const fl
       if (live && bin != lead) atomicAdd(&hist[bin], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-      int rem = s_krem, d = 255;
-      for (; d > 0; --d) {
-        if (hist[d] >= rem) break;
-        rem -= hist[d];
+    // which digit holds the rank-th largest: bin d with (keys in bins above d) < rank <= (keys in bins above d) + hist[d].
+    // 256 lanes, one bin each; counts of the bins above by a suffix sum inside the wave + the totals of the waves above
+    // (thread 0 walking the 256 bins one dependent LDS read at a time was a quarter of the kernel)
+    if (tid < 256) {
+      const int hme = hist[tid];
+      int suf = hme;  // inclusive suffix sum over the wave's lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += up;
       }
-      s_prefix = prefix | ((unsigned)d << shift);
-      s_krem = rem;
+      if (lane == 0) wtot[wave] = suf;  // the wave's total
+      // (waves 0..3 only: a named barrier is not needed -- they meet at the workgroup barrier below; the totals are read after it)
+      hsuf[tid] = suf - hme;  // keys in this wave's bins above this one
     }
+    __syncthreads();
+    if (tid < 256) {
+      int above = hsuf[tid];
+      for (int w2 = wave + 1; w2 < 4; ++w2) above += wtot[w2];
+      const int rem = s_krem, hme = hist[tid];
+      if (above < rem && rem <= above + hme) {  // exactly one bin
+        s_prefix = prefix | ((unsigned)tid << shift);
+        s_krem_next = rem - above;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_krem = s_krem_next;
     __syncthreads();
   }
   const unsigned thr = s_prefix;  // the k-th largest key; eq_take of the keys equal to it are taken, lowest indices first
   const int eq_take = s_krem;
-  // compaction in index order: position = selected before me = greater before me + min(equal before me, eq_take)
+  // compaction in index order: position = selected before me = greater before me + min(equal before me, eq_take).  Every wave
+  // owns a contiguous segment of the row: it counts its segment, ONE barrier publishes the counts, and it then walks the
+  // segment again with running counters (a prefix over the 16 waves per 1024-key chunk cost 32 LDS reads and a barrier per chunk).
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  int gt_seen = 0, eq_seen = 0;  // over the chunks so far (every thread keeps the same totals)
-  for (int c0 = 0, pp = 0; c0 < n; c0 += kSelThreads, pp ^= 1) {
-    const int i = c0 + tid;
-    const unsigned key = i < n ? keys[i] : 0u;
-    const bool gt = i < n && key > thr, eq = i < n && key == thr;
-    const unsigned long long mg = __builtin_amdgcn_ballot_w64(gt), me = __builtin_amdgcn_ballot_w64(eq);
-    if (lane == 0) {
-      wcnt[pp][0][wave] = __builtin_popcountll(mg);
-      wcnt[pp][1][wave] = __builtin_popcountll(me);
-    }
-    __syncthreads();  // (one barrier per chunk: the counts ping-pong between two buffers)
-    int gt_before = gt_seen + __builtin_popcountll(mg & lt), eq_before = eq_seen + __builtin_popcountll(me & lt);
-    int gt_total = 0, eq_total = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) {
-      const int cg = wcnt[pp][0][w2], ce = wcnt[pp][1][w2];
-      if (w2 < wave) {
-        gt_before += cg;
-        eq_before += ce;
-      }
-      gt_total += cg;
-      eq_total += ce;
-    }
-    // the output position replaces the key (0xffffffff: not selected); the copies follow in a loop without barriers
-    if (i < n) keys[i] = (gt || (eq && eq_before < eq_take)) ? (unsigned)(gt_before + (eq_before < eq_take ? eq_before : eq_take)) : 0xffffffffu;
-    gt_seen += gt_total;
-    eq_seen += eq_total;
+  constexpr int kW = kSelThreads / 64;
+  const int seg = ((n + kW - 1) / kW + 63) & ~63, s_lo = wave * seg, s_hi = s_lo + seg < n ? s_lo + seg : n;
+  int gt_cnt = 0, eq_cnt = 0;
+  for (int i0 = s_lo; i0 < s_hi; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned key = i < s_hi ? keys[i] : 0u;
+    gt_cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < s_hi && key > thr));
+    eq_cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < s_hi && key == thr));
   }
-  // (each thread reads back only what it wrote itself: no barrier needed)
+  if (lane == 0) {
+    wcnt[0][wave] = gt_cnt;
+    wcnt[1][wave] = eq_cnt;
+  }
+  __syncthreads();
+  int gt_seen = 0, eq_seen = 0;
+  for (int w2 = 0; w2 < wave; ++w2) {
+    gt_seen += wcnt[0][w2];
+    eq_seen += wcnt[1][w2];
+  }
+  for (int i0 = s_lo; i0 < s_hi; i0 += 64) {
+    const int i = i0 + lane;
+    const unsigned key = i < s_hi ? keys[i] : 0u;
+    const bool gt = i < s_hi && key > thr, eq = i < s_hi && key == thr;
+    const unsigned long long mg = __builtin_amdgcn_ballot_w64(gt), me = __builtin_amdgcn_ballot_w64(eq);
+    const int gt_before = gt_seen + __builtin_popcountll(mg & lt), eq_before = eq_seen + __builtin_popcountll(me & lt);
+    // the output position replaces the key (0xffffffff: not selected); the copies follow in a loop of their own
+    if (i < s_hi) keys[i] = (gt || (eq && eq_before < eq_take)) ? (unsigned)(gt_before + (eq_before < eq_take ? eq_before : eq_take)) : 0xffffffffu;
+    gt_seen += __builtin_popcountll(mg);
+    eq_seen += __builtin_popcountll(me);
+  }
+  __syncthreads();
   for (int i0 = tid; i0 < n; i0 += 8 * kSelThreads) {
     float2 v[8];
     unsigned pos[8];

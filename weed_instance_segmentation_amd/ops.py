@@ -1192,7 +1192,7 @@ def select_top_points(score: torch.Tensor, pts: torch.Tensor, k: int, out_points
     with torch.cuda.device(score.device):
         rc = _timed("select_top_points", score, lambda: load().wm2f_select_top_points(_p(score), _p(pts), _p(out), R, n, int(k), P, _stream(score)))
     if rc == _lib.WM2F_EUNSUPPORTED:  # more candidates per row than LDS holds: the stock sort
-        idx = torch.topk(score, k=k, dim=1)[1]
+        idx = torch.sort(torch.topk(score, k=k, dim=1)[1], dim=1)[0]  # index order, as the kernel writes them
         out[:, :k] = torch.gather(pts, 1, idx[..., None].expand(-1, -1, 2))
         return out
     check(rc, "wm2f_select_top_points")
