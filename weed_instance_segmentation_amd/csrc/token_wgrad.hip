@@ -342,14 +342,25 @@ __global__ __launch_bounds__(256) void token_wgrad_reduce_kernel(const float* __
     for (int g = 1; g < kRedGroups; ++g) t += part[g][tx];
     *reinterpret_cast<f32x4*>(dw + (size_t)n * K + k4 * 4) = t;
   }
-  // bias: the first ceil(N / 256) workgroups, one thread per feature, splits in ascending order
-  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (db && id < N) {
-    const int nb = (int)id;
-    const float* p = ws_b + (size_t)(nb / kTile) * splits * kTile + (nb % kTile);
+  // bias: the first ceil(N / 16) workgroups, 16 features each; thread row ty adds every 16th split in ascending order (its loads
+  // independent of each other), the 16 rows are added in row order through LDS.  (One thread per feature walking all the splits
+  // one dependent load at a time made the workgroups that carried the bias the kernel's critical path: 52 us for a 15-us pass.)
+  if (db && (long long)blockIdx.x * kRedCols < N) {
+    __shared__ float bpart[kRedGroups][kRedCols];
+    const int nb = blockIdx.x * kRedCols + tx;
     float sb = 0.f;
-    for (int i = 0; i < splits; ++i) sb += p[(size_t)i * kTile];
-    db[nb] = sb;
+    if (nb < N) {
+      const float* p = ws_b + (size_t)(nb / kTile) * splits * kTile + (nb % kTile);
+      for (int i = ty; i < splits; i += kRedGroups) sb += p[(size_t)i * kTile];
+    }
+    bpart[ty][tx] = sb;
+    __syncthreads();
+    if (ty == 0 && nb < N) {
+      float t = bpart[0][tx];
+#pragma unroll
+      for (int g = 1; g < kRedGroups; ++g) t += bpart[g][tx];
+      db[nb] = t;
+    }
   }
 }
 
