@@ -306,6 +306,9 @@ int wm2f_point_sample_bwd(const void* grad_out, const void* pts, const void* map
  * wm2f_add_layernorm: out = LayerNorm(x + residual) * gamma + beta over rows of C = 256 (HF:1076-1078,
  *                     :1086-1088); residual may be NULL; if out_plus_pos != NULL it receives
  *                     out + pos[row % pos_rows] (the next layer's `hidden + pos`, HF:972). */
+/* out[b][i] = a[b][i] + p[i], b < B, i < n (fp32, n % 4 == 0, 16-byte aligned): a level's positional embedding added to its tokens
+ * for every image of the batch -- the keys of the masked cross-attention, `with_pos_embed` at HF:1644-1650 (inference). */
+int wm2f_add_broadcast(const void* a, const void* p, void* out, int B, int64_t n, void* stream);
 int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y, int N, int C, int HW,
                   int relu, void* stream);
 int wm2f_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta,

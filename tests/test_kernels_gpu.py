@@ -793,6 +793,13 @@ def test_select_top_points_equals_topk_set(ops, R, n, k):
     assert torch.equal(torch.sort(torch.gather(key, 1, ref_idx), dim=1, descending=True)[0], tk)
 
 
+@pytest.mark.parametrize("B,N,C", [(3, 1000, 256), (2, 37, 4), (1, 5, 8)])
+def test_add_broadcast(ops, B, N, C):
+    g = torch.Generator().manual_seed(29)
+    a, p = torch.randn(B, N, C, generator=g), torch.randn(1, N, C, generator=g)
+    assert torch.equal(ops.add_broadcast(dev(a), dev(p)).cpu(), a + p)
+
+
 # ----------------------------------------------------------------------------------------- point sampling
 def test_point_sample_fwd_bwd(ops):
     g = torch.Generator().manual_seed(9)

@@ -69,6 +69,7 @@ SIGNATURES = {
     "wm2f_matcher_cost_levels": (c_int, [POINTER(c_void_p), _P, _P, _I, _HOST_I32, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I,
                                          _I, _I, _I, c_float, c_float, c_float, _P]),
     "wm2f_lsa_batched": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm2f_add_broadcast": (c_int, [_P, _P, _P, _I, c_int64, _P]),
     "wm2f_bias_act": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm2f_add_layernorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _I, c_int64, c_float, _P]),
     "wm2f_add_layernorm_train_workspace": (c_int64, [c_int64]),

@@ -112,6 +112,42 @@ __global__ __launch_bounds__(256) void add_layernorm256_kernel(const float* __re
 
 using namespace wm2f;
 
+// out[b][i] = a[b][i] + p[i]: the positional embedding of a level added to its tokens for every image of the batch (the keys of
+// the masked cross-attention, HF:1644-1650 `with_pos_embed`).  The stock broadcast add runs this at 1.1 TB/s (a strided kernel,
+// one element per lane); here 16 bytes per lane, 4 independent pieces in flight.
+namespace wm2f {
+namespace {
+__global__ __launch_bounds__(256) void add_broadcast_kernel(const float4* __restrict__ a, const float4* __restrict__ p,
+                                                            float4* __restrict__ out, int64_t n4) {
+  const int64_t base = (int64_t)blockIdx.y * n4;
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  float4 va[4], vp[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (i0 + e < n4) {
+      va[e] = a[base + i0 + e];
+      vp[e] = p[i0 + e];
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (i0 + e < n4) out[base + i0 + e] = make_float4(va[e].x + vp[e].x, va[e].y + vp[e].y, va[e].z + vp[e].z, va[e].w + vp[e].w);
+}
+}  // namespace
+}  // namespace wm2f
+
+extern "C" int wm2f_add_broadcast(const void* a, const void* p, void* out, int B, int64_t n, void* stream) {
+  const char* who = "wm2f_add_broadcast";
+  WM2F_REQUIRE(a && p && out, "%s: null pointer", who);
+  WM2F_REQUIRE(B > 0 && B < 65536 && n > 0 && n % 4 == 0, "%s: B = %d, n = %lld (n must be a multiple of 4)", who, B, (long long)n);
+  WM2F_REQUIRE((((uintptr_t)a | (uintptr_t)p | (uintptr_t)out) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+  const int64_t n4 = n / 4, blocks = (n4 + 1023) / 1024;
+  WM2F_REQUIRE(blocks < (int64_t(1) << 31), "%s: row too long", who);
+  hipLaunchKernelGGL(wm2f::add_broadcast_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
+                     (const float4*)p, (float4*)out, n4);
+  WM2F_CHECK_LAUNCH(who);
+  return WM2F_OK;
+}
+
 extern "C" int wm2f_bias_act(const void* x, const void* bias, const void* residual, void* y, int N, int C, int HW,
                              int relu, void* stream) {
   const char* who = "wm2f_bias_act";

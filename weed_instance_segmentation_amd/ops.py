@@ -767,6 +767,19 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor | None
     return x
 
 
+def add_broadcast(a: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """a (B, ...) + p (1, ...) -- the same trailing shape, broadcast over the batch (a level's positional embedding added to its
+    tokens, HF `with_pos_embed`).  Inference only (no autograd); fp32, element count of a row a multiple of 4."""
+    a, p = _req(a, "a"), _req(p, "p")
+    if p.shape[0] != 1 or p.shape[1:] != a.shape[1:] or (a.numel() // a.shape[0]) % 4:
+        raise ValueError(f"add_broadcast: a {tuple(a.shape)} p {tuple(p.shape)}")
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(load().wm2f_add_broadcast(_p(a), _p(p), _p(out), int(a.shape[0]), int(a.numel() // a.shape[0]), _stream(a)),
+              "wm2f_add_broadcast")
+    return out
+
+
 def add_layernorm(x, residual, gamma, beta, eps: float, pos: torch.Tensor | None = None):
     """LayerNorm(x + residual) over the last dim (= 256); with `pos` (rows_per_image, 256) also returns
     out + pos broadcast over the batch.  Inference only (no autograd)."""
