@@ -58,10 +58,11 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-# Mixed precision (BASELINE configs 3-5 run under bf16 autocast): the kernels compute in fp32, so under
-# `torch.autocast` their inputs are cast to fp32 and autocast is switched off inside -- the policy PyTorch itself
-# applies to grid_sample / softmax / layer_norm, which is what the dependency's K1 runs through.  Native bf16
-# storage for K1-K3 is a later round's work.
+# Mixed precision (BASELINE configs 3-5 run under bf16 autocast): the fp32 entry points below get their inputs cast to
+# fp32 with autocast switched off inside -- the policy PyTorch itself applies to grid_sample / softmax / layer_norm,
+# which is what the dependency's K1 runs through.  The train step's own paths do not go through these casts: K1 takes
+# the projection's rows in bf16 and writes bf16 (ms_deform_attn_rows), K2 and K3 run on the bf16 matrix cores
+# (masked_xattn_bf16, mask_einsum_bf16), the token Linears' weight gradients read bf16 operands (token_wgrad).
 _amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 
