@@ -370,11 +370,28 @@ class SelfAttention(nn.Module):
         self.q_proj = nn.Linear(embed_dim, embed_dim)
         self.out_proj = nn.Linear(embed_dim, embed_dim)
 
+    def _qk_weight(self):
+        """Inference: [q_proj * scaling ; k_proj] as ONE (2E, E) projection of h + qpos (two GEMM launches and the scaling pass
+        become one GEMM); cached per parameter version."""
+        qp, kp = self.q_proj, self.k_proj
+        key = (qp.weight._version, qp.bias._version, kp.weight._version, kp.bias._version, qp.weight.device, qp.weight.dtype)
+        c = self.__dict__.setdefault("_qk", {})
+        if c.get("key") != key:
+            with torch.no_grad():
+                c.update(key=key, w=torch.cat([qp.weight * self.scaling, kp.weight], 0).contiguous(),
+                         b=torch.cat([qp.bias * self.scaling, kp.bias], 0).contiguous())
+        return c["w"], c["b"]
+
     def forward(self, h, qpos):
         B, Q, E = h.shape
         hq = h + qpos
         sh = lambda t: t.view(B, Q, self.num_heads, self.head_dim).transpose(1, 2)
-        q, k, v = sh(self.q_proj(hq) * self.scaling), sh(self.k_proj(hq)), sh(self.v_proj(h))
+        if not torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda"):
+            w, bqk = self._qk_weight()
+            qk = F.linear(hq, w, bqk)
+            q, k, v = sh(qk[..., :E]), sh(qk[..., E:]), sh(self.v_proj(h))
+        else:
+            q, k, v = sh(self.q_proj(hq) * self.scaling), sh(self.k_proj(hq)), sh(self.v_proj(h))
         a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)), -1)
         return self.out_proj(torch.matmul(a, v).transpose(1, 2).reshape(B, Q, E))
 
@@ -402,9 +419,23 @@ class MaskedCrossAttention(nn.Module):
         v = ops.linear_tokens(value_in, self.in_proj_weight[2 * E:], self.in_proj_bias[2 * E:])
         return k, v
 
+    def _q_weight(self):
+        """Inference: the query projection with 1 / sqrt(head_dim) folded in (one launch less per layer); cached per version."""
+        E = self.embed_dim
+        key = (self.in_proj_weight._version, self.in_proj_bias._version, self.in_proj_weight.device, self.in_proj_weight.dtype)
+        c = self.__dict__.setdefault("_qw", {})
+        if c.get("key") != key:
+            with torch.no_grad():
+                sc = 1.0 / math.sqrt(self.head_dim)
+                c.update(key=key, w=(self.in_proj_weight[:E] * sc).contiguous(), b=(self.in_proj_bias[:E] * sc).contiguous())
+        return c["w"], c["b"]
+
     def forward(self, query_in, k, v, mask, row_open):
         E = self.embed_dim
-        q = F.linear(query_in, self.in_proj_weight[:E], self.in_proj_bias[:E]) * (1.0 / math.sqrt(self.head_dim))
+        if not torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda"):
+            q = F.linear(query_in, *self._q_weight())
+        else:
+            q = F.linear(query_in, self.in_proj_weight[:E], self.in_proj_bias[:E]) * (1.0 / math.sqrt(self.head_dim))
         ctx = ops.masked_xattn(q, k, v, mask, row_open, self.num_heads)
         return self.out_proj(ctx)
 
