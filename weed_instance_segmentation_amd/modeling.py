@@ -68,6 +68,7 @@ _POS_CACHE: dict = {}
 # traffic of a K1 launch 1.29 x -> 1.005 x its algorithmic bytes, 156 -> 138 us in the model.  Either one alone gains
 # nothing (head-major rows under the old order: round 2; slab order on token-major rows re-fetches every 1152-byte row
 # once per head).  Plain module attributes -- tools/ flip them for A/B runs; the package reads no environment.
+SDPA_SELF_ATTENTION = True  # inference: the 100 x 100 self-attention through the stock fused attention op (-0.28 ms per forward; tools/probes/sdpa_self_attention_probe.py)
 HEAD_MAJOR_ROWS = True
 HEAD_MAJOR_VALUE = False  # value (heads, B, S, 32) from the token GEMM too: A/B only (tools/k1_slab_inmodel.py)
 
@@ -390,6 +391,9 @@ class SelfAttention(nn.Module):
             w, bqk = self._qk_weight()
             qk = F.linear(hq, w, bqk)
             q, k, v = sh(qk[..., :E]), sh(qk[..., E:]), sh(self.v_proj(h))
+            if SDPA_SELF_ATTENTION:  # (A/B switch for tools/: the fused attention op of the stock library)
+                a = F.scaled_dot_product_attention(q, k, v, scale=1.0)
+                return self.out_proj(a.transpose(1, 2).reshape(B, Q, E))
         else:
             q, k, v = sh(self.q_proj(hq) * self.scaling), sh(self.k_proj(hq)), sh(self.v_proj(h))
         a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)), -1)
