@@ -128,6 +128,8 @@ def test_fused_pass_ops_refuse_cpu_tensors():
         lambda: ops.bias_relu_maxpool(x, b),
         lambda: ops.resize_bilinear(x, (4, 4)),
         lambda: ops.tokens_to_nchw(torch.randn(1, 64, 8), 0, 8, 8),
+        lambda: ops.add_broadcast(torch.randn(2, 5, 8), torch.randn(1, 5, 8)),
+        lambda: ops.select_top_points(torch.randn(2, 16), torch.rand(2, 16, 2), 4),
     ]
     for call in calls:
         with pytest.raises(Wm2fError):
@@ -336,3 +338,27 @@ def test_lsa_transcription_equals_scipy():
         r0, c0 = linear_sum_assignment(c)
         r1, c1 = _lsa_transcription(c)
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+
+
+def test_k1_rows_op_host_logic():
+    """The training K1 op has no CPU form: the shape test says so for host tensors (the module then composes the op from stock
+    autograd ops, which is what runs on a CPU), and calling it anyway raises instead of computing."""
+    from weed_instance_segmentation_amd import ops
+    shapes = [(2, 2), (4, 4), (8, 8)]
+    S = sum(h * w for h, w in shapes)
+    value, rows = torch.randn(1, S, 8, 32), torch.randn(1, S, 8 * 36)
+    assert not ops.k1_rows_applies(value, rows, shapes, 8)
+    with pytest.raises(ValueError):
+        ops.ms_deform_attn_rows(value, shapes, rows, 8)
+    assert ops.k1_lanes_applies(shapes, S, 32, 4, 1, 8) and not ops.k1_lanes_applies([(2, 2), (4, 4), (8, 9)], 4 + 16 + 72, 32, 4, 1, 8)
+
+
+def test_uncertain_points_host_route_is_the_dependency_topk():
+    """loss._uncertain_points on host tensors: HF:688-704's topk + gather, in the first n_unc slots of the (rows, P, 2) result."""
+    from weed_instance_segmentation_amd.loss import Mask2FormerLoss
+    g = torch.Generator().manual_seed(3)
+    unc, pc = -torch.rand(3, 40, generator=g), torch.rand(3, 40, 2, generator=g)
+    pts = Mask2FormerLoss._uncertain_points(unc, pc, 10, 16)
+    assert pts.shape == (3, 16, 2)
+    idx = torch.topk(unc, 10, dim=1)[1]
+    assert torch.equal(pts[:, :10], torch.gather(pc, 1, idx[..., None].expand(-1, -1, 2)))
