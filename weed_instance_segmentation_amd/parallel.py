@@ -230,7 +230,12 @@ class DataParallelEngine:
             for t in list(model.parameters()) + list(model.buffers()):
                 broadcast_from(t.data, 0, process_group)
         self.buckets = GradBuckets(model.parameters(), bucket_bytes, process_group, exchange)
-        self.optimizer = optimizer or torch.optim.AdamW(model.parameters(), lr=lr)  # train.py:174
+        if optimizer is None:  # train.py:174 (AdamW, lr 5e-5).  On a GPU the fused form: ONE kernel over all parameters instead of
+            # the multi-tensor form's ~14 launches per 1k tensors (1.7 -> 0.3 ms per config-2 step); same update rule
+            params = list(model.parameters())
+            fused = bool(params) and all(p.is_cuda and p.is_floating_point() for p in params)
+            optimizer = torch.optim.AdamW(params, lr=lr, fused=True) if fused else torch.optim.AdamW(params, lr=lr)
+        self.optimizer = optimizer
         self._micro = 0
         crit = getattr(model, "criterion", None)
         if crit is not None and hasattr(crit, "world_size_fn"):
