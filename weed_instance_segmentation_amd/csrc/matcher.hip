@@ -307,16 +307,16 @@ __global__ __launch_bounds__(1024) void matcher_group_points_kernel(const float*
   }
 }
 
-template <bool VEC4>
+template <bool VEC4, int QG>
 __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
     MatcherLevels levels, const float* __restrict__ class_logits, const float* __restrict__ tm,
     const int64_t* __restrict__ tgt_classes, const float* __restrict__ points, const int* __restrict__ band_off,
     float* __restrict__ cost, MatcherImages im, int B, int Q, int C1, int h, int w, int P, int Tsum, int Tmax, int R, int NB,
     float w_class, float w_mask, float w_dice) {
-  constexpr int NV = kQG * kTC * 3 + kTC + kQG * 2;  // values reduced per chunk
+  constexpr int NV = QG * kTC * 3 + kTC + QG * 2;  // values reduced per chunk
   __shared__ float red[4][NV];
-  extern __shared__ __attribute__((aligned(16))) float band[];  // [kQG][(R + 1) * w rounded up to 256]
-  const int b = blockIdx.z, lvl = blockIdx.y, q0 = blockIdx.x * kQG;
+  extern __shared__ __attribute__((aligned(16))) float band[];  // [QG][(R + 1) * w rounded up to 256]
+  const int b = blockIdx.z, lvl = blockIdx.y, q0 = blockIdx.x * QG;
   const int t_begin = im.off[b], T = im.off[b + 1] - t_begin;
   if (T <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,15 +330,15 @@ __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
   const int band_elems = (R + 1) * w, band_stride = (band_elems + 255) & ~255;  // whole 1-KiB pieces per map
 
   for (int t0 = 0; t0 < T; t0 += kTC) {
-    float a_pos[kQG][kTC], a_neg[kQG][kTC], a_sig[kQG][kTC], s_t[kTC], s_neg[kQG], s_sig[kQG];
+    float a_pos[QG][kTC], a_neg[QG][kTC], a_sig[QG][kTC], s_t[kTC], s_neg[QG], s_sig[QG];
 #pragma unroll
     for (int c = 0; c < kTC; ++c) {
       s_t[c] = 0.f;
 #pragma unroll
-      for (int qq = 0; qq < kQG; ++qq) a_pos[qq][c] = a_neg[qq][c] = a_sig[qq][c] = 0.f;
+      for (int qq = 0; qq < QG; ++qq) a_pos[qq][c] = a_neg[qq][c] = a_sig[qq][c] = 0.f;
     }
 #pragma unroll
-    for (int qq = 0; qq < kQG; ++qq) s_neg[qq] = s_sig[qq] = 0.f;
+    for (int qq = 0; qq < QG; ++qq) s_neg[qq] = s_sig[qq] = 0.f;
 
     for (int k = 0; k < NB; ++k) {
       const int p_lo = boff[k], p_hi = boff[k + 1];
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
       __syncthreads();             // the previous band's samples are taken
       const int row0 = k * R;
 #pragma unroll
-      for (int qq = 0; qq < kQG; ++qq) {
+      for (int qq = 0; qq < QG; ++qq) {
         int qi = q0 + qq;
         if (qi > Q - 1) qi = Q - 1;
         const float* src = ml + (int64_t)qi * h * w + (int64_t)row0 * w;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
         const bool xl = in && x0 >= 0, xr = in && x0 + 1 < w, yt = y0 >= 0, yb = y0 + 1 < h;
         const int o = in ? (y0 - row0) * w + x0 : 0;
 #pragma unroll
-        for (int qq = 0; qq < kQG; ++qq) {
+        for (int qq = 0; qq < QG; ++qq) {
           const float* pb = band + qq * band_stride + o;
           float xs = 0.f;
           if (yt && xl) xs += pb[0] * (fx0 * fy0);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
       ++vi;
     };
 #pragma unroll
-    for (int qq = 0; qq < kQG; ++qq)
+    for (int qq = 0; qq < QG; ++qq)
 #pragma unroll
       for (int c = 0; c < kTC; ++c) {
         put(a_pos[qq][c]);
@@ -429,20 +429,20 @@ __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
 #pragma unroll
     for (int c = 0; c < kTC; ++c) put(s_t[c]);
 #pragma unroll
-    for (int qq = 0; qq < kQG; ++qq) {
+    for (int qq = 0; qq < QG; ++qq) {
       put(s_neg[qq]);
       put(s_sig[qq]);
     }
     __syncthreads();
-    if (threadIdx.x < kQG * kTC) {
+    if (threadIdx.x < QG * kTC) {
       const int qq = threadIdx.x / kTC, c = threadIdx.x % kTC;
       const int qi = q0 + qq, t = t0 + c;
       if (qi < Q && t < T) {
         auto Rd = [&](int i) { return (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i]; };
         const double apos = Rd((qq * kTC + c) * 3 + 0), aneg = Rd((qq * kTC + c) * 3 + 1);
         const double asig = Rd((qq * kTC + c) * 3 + 2);
-        const double st = Rd(kQG * kTC * 3 + c);
-        const double sneg = Rd(kQG * kTC * 3 + kTC + qq * 2), ssig = Rd(kQG * kTC * 3 + kTC + qq * 2 + 1);
+        const double st = Rd(QG * kTC * 3 + c);
+        const double sneg = Rd(QG * kTC * 3 + kTC + qq * 2), ssig = Rd(QG * kTC * 3 + kTC + qq * 2 + 1);
         const double cost_mask = (apos + (sneg - aneg)) / (double)P;
         const double cost_dice = 1.0 - (2.0 * asig + 1.0) / (ssig + st + 1.0);
         const float* cl = clb + (int64_t)qi * C1;
@@ -465,9 +465,12 @@ __global__ __launch_bounds__(256) void matcher_cost_band_kernel(
 }
 
 // rows per band for a map of width w (0: the band form does not apply)
+constexpr int kBandQG = 2;  // queries per workgroup in the band form.  Every query group re-reads the (level, image)'s sampled targets
+                            // from L2 (803 KB at config 2): 4 per workgroup halve that traffic (6.4 -> 3.2 GB per step next to the
+                            // 4.2 GB of maps) but measured 3.98 against 2.34 ms -- 192 accumulators per lane and half the bands' rows
 static inline int band_rows(int h, int w, int P) {
   if (P < 1024) return 0;  // few points: the gathers are not the time
-  int R = kBandLdsBytes / (kQG * w * 4) - 1;
+  int R = kBandLdsBytes / (kBandQG * w * 4) - 1;
   if (R > h) R = h;
   if (R < 8) return 0;
   return (h + R - 1) / R <= kMaxBands ? R : 0;
@@ -533,8 +536,9 @@ static int matcher_cost_impl(const MatcherLevels& levels, const void* class_logi
   }
   dim3 gb(ceil_div(Q, kQG), NL, B);
   if (R) {
-    const size_t lds = (size_t)kQG * ((((size_t)(R + 1) * w) + 255) & ~(size_t)255) * 4;
-    auto kf = (w % 4 == 0) ? matcher_cost_band_kernel<true> : matcher_cost_band_kernel<false>;
+    gb.x = ceil_div(Q, kBandQG);
+    const size_t lds = (size_t)kBandQG * ((((size_t)(R + 1) * w) + 255) & ~(size_t)255) * 4;
+    auto kf = (w % 4 == 0) ? matcher_cost_band_kernel<true, kBandQG> : matcher_cost_band_kernel<false, kBandQG>;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("%s: cannot raise dynamic LDS to %zu", who, lds);
       return WM2F_ELAUNCH;
