@@ -393,6 +393,7 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_lw_kernel(
   }
 }
 
+#ifdef WM2F_PROFILING  // superseded by the quad form below; kept as its measured baseline
 // ---------------------------------------------------------------------------------- kernel B
 // Wave-per-query.  Lanes 0..NL*P-1 each work out ONE sampling point (pixel, four weights, flags); the
 // wave then walks the points with those values as scalars (v_readlane), and every atomic instruction
@@ -559,6 +560,8 @@ __global__ __launch_bounds__(kBwdThreads) void msdeform_tiled_bwd_value_kernel(
     }
   }
 }
+
+#endif  // WM2F_PROFILING (wave-per-query value kernel)
 
 typedef __attribute__((address_space(3))) int lds_int_t;
 
@@ -949,11 +952,17 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
     *handled = true;
     return WM2F_OK;
   }
+#ifdef WM2F_PROFILING  // the wave-per-query value kernel exists in the profiling build only (A/B: WM2F_K1_BWD_OLD=1)
+#define WM2F_TB_OLD(NLv) \
+  if (old_form) kb = det_ws ? msdeform_tiled_bwd_value_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_kernel<NLv, 4, false>;
+#else
+#define WM2F_TB_OLD(NLv)
+#endif
 #define WM2F_TB(NLv)                                                                                              \
   case NLv: {                                                                                                     \
     auto ka = msdeform_tiled_bwd_lw_kernel<NLv, 4>;                                                               \
-    auto kb = old_form ? (det_ws ? msdeform_tiled_bwd_value_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_kernel<NLv, 4, false>) \
-                       : (det_ws ? msdeform_tiled_bwd_value_quad_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_quad_kernel<NLv, 4, false>); \
+    auto kb = det_ws ? msdeform_tiled_bwd_value_quad_kernel<NLv, 4, true> : msdeform_tiled_bwd_value_quad_kernel<NLv, 4, false>; \
+    WM2F_TB_OLD(NLv)                                                                                              \
     if (p.lds_bytes > 64 * 1024) {                                                                                \
       hipError_t e1 = hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
       hipError_t e2 = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes); \
@@ -977,6 +986,7 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
     default: return WM2F_OK;
   }
 #undef WM2F_TB
+#undef WM2F_TB_OLD
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: tiled backward launch failed: %s", who, hipGetErrorString(e));
