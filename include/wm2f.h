@@ -85,7 +85,7 @@ int wm2f_msdeform_bwd_det(const void* value, const void* loc, const void* attn_w
  *   rows       (B, Q, heads * L*P*3)   [offsets (heads, L, P, 2) in pixels | logits (heads, L*P)] per token, as
  *                                      cat(sampling_offsets, attention_weights) writes them
  *   out        (B, Q, heads * 32)
- *   grad_out   as out;  grad_rows as rows (every element written);  grad_value as value, ZEROED by the caller
+ *   grad_out   as out;  grad_rows as rows (every element written);  grad_value as value (need not be cleared)
  * dtype = WM2F_F32: rows, out, grad_out, grad_rows are fp32; WM2F_BF16: all four are bf16 (what a bf16-autocast Linear writes
  * and reads; bf16 -> fp32 is exact, the outputs are rounded to nearest even once).  Reference points are the tokens' pixel
  * centres (:1127-1156 with valid ratios of 1).  Forward: the streaming kernel (3 levels 1 : 2 : 4 coarse first or a pyramid

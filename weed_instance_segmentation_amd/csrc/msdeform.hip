@@ -477,7 +477,7 @@ extern "C" int wm2f_msdeform_rows_fwd(const void* value, const void* rows, void*
   return WM2F_OK;
 }
 
-// grad_value (fp32, ZEROED by the caller: the tiles add into it), grad_rows (every element written).
+// grad_value (fp32; need NOT be cleared: the first kernel clears it, the second accumulates), grad_rows (every element written).
 extern "C" int wm2f_msdeform_rows_bwd(const void* value, const void* rows, const void* grad_out, void* grad_value, void* grad_rows,
                                       const int32_t* level_hw, int B, int S, int Q, int heads, int D, int L, int P, int dtype,
                                       void* stream) {

@@ -262,6 +262,12 @@ __global__ __launch_bounds__(NT) void msdeform_tiled_bwd_lw_kernel(
       go1 = ld4g(grad_out + pair * D + 16 + j * 4);
     }
     const f32x2 gp[4] = {{go0.x, go0.y}, {go0.z, go0.w}, {go1.x, go1.y}, {go1.z, go1.w}};
+    if (ROWS && grad_w) {
+      // ROWS: `grad_w` carries grad_value, which the NEXT kernel accumulates into with atomics: this kernel, whose tiles' queries
+      // partition the tokens, clears each (token, head) row on the way -- the 352-MB fill in front of the backward is gone
+      *reinterpret_cast<float4*>(grad_w + pair * D + j * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(grad_w + pair * D + 16 + j * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // ROWS: this (query, head)'s piece of the token's row: offsets at off_e, logits at log_e (element indices)
     const int64_t row_e = ((int64_t)c.b * Q + q) * (heads * NL * P * 3);
     const int64_t off_e = row_e + c.h * (NL * P * 2), log_e = row_e + heads * (NL * P * 2) + c.h * (NL * P);
@@ -937,7 +943,7 @@ int launch_tiled_bwd(const void* value, const void* loc, const void* attn_w, con
       }
     }
     hipLaunchKernelGGL(ka, dim3(per_xcd * kNumXcd), dim3(ka_threads), p.lds_bytes, st, (const float*)value, (const float*)loc,
-                       (const float*)nullptr, (const float*)grad_out, (float*)grad_loc, (float*)nullptr, p.g, S, Q, heads, (int)n_logical, per_xcd);
+                       (const float*)nullptr, (const float*)grad_out, (float*)grad_loc, (float*)grad_value, p.g, S, Q, heads, (int)n_logical, per_xcd);
 #ifdef WM2F_PROFILING
     if (!(skip_kb || (e_lw && (atoi(e_lw) == 1 || atoi(e_lw) == 2))))
 #endif

@@ -200,7 +200,7 @@ class _MSDeformAttnRows(torch.autograd.Function):
         B, S, H, D = v32.shape
         lp = rows.dtype == torch.bfloat16
         grad_out = _req(grad_out if grad_out.dtype == rows.dtype else grad_out.to(rows.dtype), "grad_out", rows.dtype)
-        g_value = torch.zeros_like(v32)
+        g_value = torch.empty_like(v32)  # (cleared by the backward's first kernel)
         g_rows = torch.empty_like(rows)
         lv = host_i32([x for hw in ctx.level_hw for x in hw])
         with torch.cuda.device(v32.device):
